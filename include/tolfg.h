@@ -1,0 +1,190 @@
+/*
+ * tolfg.h -- C ABI of libtolfg.so, the MI355X-native implementation of tol's SNOPT user function.
+ *
+ * Everything here is plain C: pointers, sizes, opaque handles.  Citations "ref:" point into the
+ * reference tree (lingaqing/tol) and name the interface each entry point replaces.
+ *
+ * Three groups:
+ *   1. the SNOPT callback itself, DEFINEGusrfg_, byte-for-byte the reference's snFunA symbol;
+ *   2. problem set-up: what the reference's `new problemS10(args)` / `new problemG7(args)` and
+ *      problem::runSNOPT hand to SNOPT (sizes, sparsity pattern, initial guess, bounds);
+ *   3. a batched, device-resident evaluation (no reference counterpart) for many independent
+ *      trajectories per GPU.
+ *
+ * There is no CPU fallback: every evaluation entry point needs a gfx950 device and reports failure
+ * (return code / *Status) when the HIP runtime or the device is unavailable.
+ */
+#ifndef TOLFG_H_
+#define TOLFG_H_
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ return codes */
+enum {
+    TOLFG_OK            = 0,
+    TOLFG_ERR_ARG       = -1,   /* bad argument (null pointer, unknown mission, size mismatch)   */
+    TOLFG_ERR_PARAM     = -2,   /* .param file missing or wrong element count
+                                   (ref: std::length_error, src/parameters.cpp:45-67)            */
+    TOLFG_ERR_HIP       = -3,   /* HIP runtime / device failure; tolfg_last_error() has the text */
+    TOLFG_ERR_NOCURRENT = -4    /* DEFINEGusrfg_ called with no current problem                  */
+};
+
+/* thread-local text of the last failure in this library ("" when none) */
+const char *tolfg_last_error(void);
+
+/* wind models (ref: problem::modelWind, src/problem.cpp:475-531,732-735) */
+enum {
+    TOLFG_WIND_NONE  = 0,    /* case 0 */
+    TOLFG_WIND_SHEAR = 1,    /* case 1, linear boundary layer: the offline fallback (src/problem.cpp:73-78) */
+    TOLFG_WIND_TABLE = 99    /* caller-supplied per-node wind; the reference's `default:` arm       */
+};
+
+enum { TOLFG_F64 = 0, TOLFG_F32 = 1 };
+
+/* ------------------------------------------------------------------ 2. problem set-up */
+
+/* What the reference takes from argv (ref: arguments::arguments(char**), src/arguments.cpp:32-46)
+ * plus the constants it hard-codes, exposed with the reference's values as defaults when the
+ * struct is filled by tolfg_config_default(). */
+typedef struct tolfg_config {
+    const char *mission;      /* "S10" | "G7"                      ref: src/tol.cpp:9-23            */
+    const char *aircraft;     /* basename of aircraft/<name>.param ref: src/parameters.cpp:42-43    */
+    const char *root_path;    /* directory holding aircraft/ and problems/ (ref root_path,
+                                 src/arguments.cpp:45); NULL = the data shipped with this library  */
+    double east, north, up;                        /* argv[1..3], stored, unused on the path        */
+    double east_goal, north_goal, up_goal;         /* argv[4..6]  (NED goal = north, east, -up)     */
+    double radius_goal;                            /* argv[7]                                       */
+    int    ts;                /* time segments; 0 = take snopt.param's (100 as shipped)            */
+    int    windmodel;         /* TOLFG_WIND_*; reference offline behaviour = TOLFG_WIND_SHEAR      */
+    double Vref, href;        /* shear wind constants, 2.4 and 10 (ref: src/problem.cpp:504-505)   */
+    double xi, yi, zi;        /* start position, 0,0,0 (ref: src/problem.cpp:83-85,111-113)        */
+    int    device;            /* HIP device ordinal                                                */
+    int    debug_dumps;       /* 1 = also rewrite Xoutput/Foutput/Goutput.txt each call like the
+                                 reference does (src/DefineFG.cpp:16-46); default 0                */
+} tolfg_config;
+
+void tolfg_config_default(tolfg_config *cfg);
+
+typedef struct tolfg_problem tolfg_problem;
+
+/* ref: `prob = new problemS10(args)` / `new problemG7(args)`, src/tol.cpp:9-17 -- reads the four
+ * .param files, builds pattern, initial guess and bounds, allocates device and pinned buffers. */
+int  tolfg_create(const tolfg_config *cfg, tolfg_problem **out);
+/* ref: `delete prob`, src/tol.cpp:32 */
+void tolfg_destroy(tolfg_problem *p);
+
+/* Companion data the SNOPT driver needs (ref: problem::runSNOPT, src/problem.cpp:1223-1233).
+ * n, neF: src/problem.cpp:151-152; neG: what countG counts (src/problem.cpp:813-919). */
+int tolfg_sizes(const tolfg_problem *p, int *n, int *neF, int *neG);
+/* iGfun/jGvar[neG], 0-based like the reference's arrays before snoptProblemA::solve shifts them
+ * (ref: src/snoptProblem.cpp:460-465). */
+int tolfg_pattern(const tolfg_problem *p, int *iGfun, int *jGvar);
+/* ref: problemS10::InitialCond / problemG7::InitialCond */
+int tolfg_x0(const tolfg_problem *p, double *x);
+/* ref: problem::setLimits, src/problem.cpp:198-365 */
+int tolfg_bounds(const tolfg_problem *p, double *xlow, double *xupp, double *Flow, double *Fupp);
+/* ref: sn.opt_tol / sn.feas_tol handed to SNOPT, src/problem.cpp:1235-1236 */
+int tolfg_tolerances(const tolfg_problem *p, double *opt_tol, double *feas_tol);
+/* Table wind for TOLFG_WIND_TABLE: wind[f*(ts+1)+k], f = 0..11 in the order of the reference's
+ * member vectors u v w du_dx du_dy du_dz dv_dx dv_dy dv_dz dw_dx dw_dy dw_dz, ENU convention
+ * (ref: include/problem.h:103).  Copied to the device; switches the problem to table wind. */
+int tolfg_set_wind_table(tolfg_problem *p, const double *wind_enu);
+
+/* ------------------------------------------------------------------ 1. the SNOPT callback */
+
+/* ref: `problem *prob` global, src/tol.cpp:3 / include/global_objects.h:5.  The callback evaluates
+ * the current problem.  (If iu != NULL and *leniu >= 2 and iu[0] == TOLFG_IU_MAGIC the callback
+ * instead uses the handle index in iu[1] -- see tolfg_handle_index -- so several problems can be
+ * solved from one process; tol itself never sets user workspace.) */
+void           tolfg_set_current(tolfg_problem *p);
+tolfg_problem *tolfg_get_current(void);
+#define TOLFG_IU_MAGIC 0x70F6
+int            tolfg_handle_index(const tolfg_problem *p);
+
+/* ref: include/DefineFG.h:9-14, assignable to snFunA (include/snopt/snopt.h:60-66).
+ * Reads x[0..*n), writes F[0..*neF) iff *needF > 0 and G[0..*neG) iff *needG > 0, complete on
+ * return.  The reference never touches *Status; this build sets *Status = -2 (snOptA: terminate)
+ * on a HIP failure or size mismatch and leaves it untouched otherwise. */
+void DEFINEGusrfg_(int *Status, int *n, double x[],
+                   int *needF, int *neF, double F[],
+                   int *needG, int *neG, double G[],
+                   char *cu, int *lencu,
+                   int iu[], int *leniu,
+                   double ru[], int *lenru);
+
+/* The three public methods DEFINEGusrfg_ dispatches to in the reference
+ * (ref: problem::modelWind / computeF / computeG, src/problem.cpp:475,765,782), for callers that
+ * drive them separately.  modelWind stages x on the device; computeF / computeG evaluate on demand
+ * (one fused launch serves both when they follow the same modelWind). */
+int tolfg_modelWind(tolfg_problem *p, const double *x);
+int tolfg_computeF(tolfg_problem *p, const double *x, double *F);
+int tolfg_computeG(tolfg_problem *p, const double *x, double *G);
+
+/* ------------------------------------------------------------------ 3. batched evaluation */
+
+/* One trajectory of a batch.  All trajectories of a batch share mission and ts. */
+typedef struct tolfg_traj {
+    int    aircraft;          /* index into tolfg_batch_config.aircraft[]                          */
+    int    reserved;
+    double Vref, href;        /* shear wind of this trajectory (TOLFG_WIND_SHEAR)                  */
+    double north_goal, east_goal, radius_goal;
+    double xi, yi;            /* start position: G7's course chi_d = atan2(yg-yi, xg-xi)           */
+} tolfg_traj;
+
+typedef struct tolfg_batch_config {
+    const char        *mission;
+    const char        *root_path;     /* NULL = shipped data                                      */
+    const char *const *aircraft;      /* aircraft table: names of .param files                     */
+    int                n_aircraft;    /* 1..8                                                      */
+    int                ts;            /* 0 = snopt.param's                                         */
+    int                windmodel;
+    int                dtype;         /* TOLFG_F64 | TOLFG_F32: element type of X, F, G, wind      */
+    int                device;
+} tolfg_batch_config;
+
+typedef struct tolfg_batch tolfg_batch;
+
+int  tolfg_batch_create(const tolfg_batch_config *cfg, tolfg_batch **out);
+void tolfg_batch_destroy(tolfg_batch *b);
+int  tolfg_batch_sizes(const tolfg_batch *b, int *n, int *neF, int *neG);
+int  tolfg_batch_pattern(const tolfg_batch *b, int *iGfun, int *jGvar);
+/* Describe (or re-describe) the B trajectories; uploads a small per-trajectory table. */
+int  tolfg_batch_set_trajectories(tolfg_batch *b, int B, const tolfg_traj *trajs);
+/* initial guess of trajectory t (host, double) -- the reference's InitialCond with (xi,yi,zi) */
+int  tolfg_batch_x0(const tolfg_batch *b, int t, double zi, double *x);
+/* bounds of trajectory t (ref: problem::setLimits), any pointer may be NULL */
+int  tolfg_batch_bounds(const tolfg_batch *b, int t, double zi,
+                        double *xlow, double *xupp, double *Flow, double *Fupp);
+
+/* Evaluate F and G of trajectories [0,B) in one launch.  dX, dF, dG, dWind are DEVICE pointers to
+ * elements of the batch dtype; row t of X/F/G starts ldx/ldf/ldg elements after row t-1
+ * (ld >= n / neF / neG; even ld keeps 16-byte stores).  dWind is NULL unless windmodel is
+ * TOLFG_WIND_TABLE, then [B][12][ts+1].  stream is a hipStream_t (NULL = default stream).
+ * Asynchronous: returns after enqueueing. */
+int  tolfg_batch_eval(tolfg_batch *b, int B,
+                      const void *dX, long ldx, void *dF, long ldf, void *dG, long ldg,
+                      const void *dWind, int needF, int needG, void *stream);
+/* dObj[t] = F[t][0] for t in [0,B): the per-trajectory objectives, contiguous, ready for the
+ * RCCL all-gather across GPUs. */
+int  tolfg_batch_objectives(tolfg_batch *b, int B, const void *dF, long ldf, void *dObj, void *stream);
+
+/* algorithmic bytes one evaluation of B trajectories moves: elemsize * B * (n + neF + neG)
+ *  */
+double tolfg_batch_algorithmic_bytes(const tolfg_batch *b, int B);
+
+/* ------------------------------------------------------------------ misc */
+/* directory of the .param data shipped with the library (tol_amd/data) */
+const char *tolfg_default_root(void);
+/* .param reader (ref: parameters::readparams, src/parameters.cpp:14-34).  Returns the number of
+ * values found (may exceed maxn; only maxn are stored) or TOLFG_ERR_PARAM if unreadable. */
+int tolfg_read_params(const char *path, double *out, int maxn);
+const char *tolfg_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TOLFG_H_ */

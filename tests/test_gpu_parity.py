@@ -1,0 +1,146 @@
+"""HIP path vs oracle, through the C ABI (DEFINEGusrfg_ and the batched entry points)."""
+import numpy as np
+import pytest
+
+from helpers import assert_close, random_wind_table
+
+pytestmark = pytest.mark.gpu
+
+AIRCRAFT = ["tempest", "skywalker", "tempest_eric", "tempest_wences", "tempest_will"]
+
+
+def _goal(mission):
+    return dict(east_goal=400.0, north_goal=0.0, radius_goal=100.0 if mission == "S10" else 0.0)
+
+
+@pytest.mark.parametrize("mission", ["S10", "G7"])
+@pytest.mark.parametrize("N", [1, 2, 3, 63, 64, 65, 100, 127, 128, 200, 333])
+def test_callback_matches_oracle(tolfg, oracle, mission, N):
+    """DEFINEGusrfg_ with SNOPT's calling convention at x0 and at seeded perturbed points."""
+    p = tolfg.Problem(mission, "tempest", ts=N, **_goal(mission))
+    o = oracle.Problem(mission, "tempest", N=N, **_goal(mission))
+    mask = o.undefined_mask()
+    pts = [o.x0()] + [oracle.perturbed(o, seed) for seed in (7, 8, 9)]
+    for i, x in enumerate(pts):
+        F, G, st = p.define_fg(x)
+        assert st == 1
+        Fo, Go = o.eval(x)
+        assert_close(F, Fo, what=f"{mission} N={N} pt{i} F")
+        assert_close(G, Go, mask=mask, what=f"{mission} N={N} pt{i} G")
+        assert (G[mask] == 0.0).all()      # the reference's undefined slots are defined as 0 here
+    p.close()
+
+
+@pytest.mark.parametrize("mission", ["S10", "G7"])
+@pytest.mark.parametrize("aircraft", AIRCRAFT)
+@pytest.mark.parametrize("wind", ["none", "shear", "table"])
+def test_airframes_and_wind_models(tolfg, oracle, mission, aircraft, wind):
+    N = 100
+    wm = {"none": 0, "shear": 1, "table": 1}[wind]
+    p = tolfg.Problem(mission, aircraft, ts=N, windmodel=wm, Vref=3.1, href=12.5, **_goal(mission))
+    table = random_wind_table(N, 11) if wind == "table" else None
+    o = oracle.Problem(mission, aircraft, N=N, windmodel=wm, Vref=3.1, href=12.5, wind_table=table, **_goal(mission))
+    if table is not None:
+        p.set_wind_table(table)
+    mask = o.undefined_mask()
+    for seed in (21, 22):
+        x = oracle.perturbed(o, seed)
+        F, G, st = p.define_fg(x)
+        assert st == 1
+        Fo, Go = o.eval(x)
+        assert_close(F, Fo, what=f"{mission}/{aircraft}/{wind} F")
+        assert_close(G, Go, mask=mask, what=f"{mission}/{aircraft}/{wind} G")
+    p.close()
+
+
+def test_need_flags_and_untouched_outputs(tolfg, oracle):
+    """needF/needG = 0 must leave the corresponding array untouched (src/DefineFG.cpp:26,36)."""
+    p = tolfg.Problem("S10", "tempest", ts=100, **_goal("S10"))
+    o = oracle.Problem("S10", "tempest", N=100, **_goal("S10"))
+    x = oracle.perturbed(o, 5)
+    Fo, Go = o.eval(x)
+    F, G, st = p.define_fg(x, needF=True, needG=False)
+    assert_close(F, Fo, what="F only")
+    assert (G == 0).all()
+    F, G, st = p.define_fg(x, needF=False, needG=True)
+    assert (F == 0).all()
+    assert_close(G, Go, mask=o.undefined_mask(), what="G only")
+    F, G, st = p.define_fg(x, needF=False, needG=False)
+    assert (F == 0).all() and (G == 0).all() and st == 1
+    p.close()
+
+
+def test_three_methods_and_iu_route(tolfg, oracle):
+    """modelWind/computeF/computeG driven separately, and two problems alive at once via iu[]."""
+    a = tolfg.Problem("S10", "tempest", ts=100, **_goal("S10"))
+    b = tolfg.Problem("G7", "skywalker", ts=64, **_goal("G7"))
+    oa = oracle.Problem("S10", "tempest", N=100, **_goal("S10"))
+    ob = oracle.Problem("G7", "skywalker", N=64, **_goal("G7"))
+    xa, xb = oracle.perturbed(oa, 1), oracle.perturbed(ob, 2)
+    a.modelWind(xa)
+    assert_close(a.computeF(xa), oa.eval(xa)[0], what="computeF")
+    assert_close(a.computeG(xa), oa.eval(xa)[1], mask=oa.undefined_mask(), what="computeG")
+    xa2 = oracle.perturbed(oa, 3)           # computeG with an x that was never staged
+    assert_close(a.computeG(xa2), oa.eval(xa2)[1], mask=oa.undefined_mask(), what="computeG restage")
+    a.make_current()
+    Fb, Gb, st = b.define_fg(xb, use_iu=True)   # current is `a`, iu[] selects `b`
+    assert st == 1
+    assert_close(Fb, ob.eval(xb)[0], what="iu F")
+    assert_close(Gb, ob.eval(xb)[1], what="iu G")
+    a.close(); b.close()
+
+
+def test_size_mismatch_sets_status(tolfg):
+    import ctypes as C
+    p = tolfg.Problem("S10", "tempest", ts=100, **_goal("S10"))
+    x = p.x0()[:-1].copy()
+    F, G, st = p.define_fg(x)
+    assert st == -2
+    p.close()
+
+
+@pytest.mark.parametrize("mission", ["S10", "G7"])
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("pad", [None, 1])
+def test_batch_matches_oracle(tolfg, oracle, mission, dtype, pad):
+    """Mixed airframes, per-trajectory shear wind and goals, ragged B, aligned and unaligned rows."""
+    import torch
+    N, B = 200, 37
+    rng = np.random.default_rng(123)
+    bt = tolfg.Batch(mission, AIRCRAFT, ts=N, dtype=dtype)
+    trajs, oprobs, X = [], [], []
+    for t in range(B):
+        tr = tolfg.Trajectory(aircraft=t % 5, Vref=rng.uniform(0, 5), href=rng.uniform(5, 20),
+                              north_goal=rng.uniform(-50, 50), east_goal=rng.uniform(300, 500),
+                              radius_goal=(rng.uniform(50, 150) if mission == "S10" else 0.0),
+                              xi=rng.uniform(-50, 50), yi=rng.uniform(-50, 50))
+        trajs.append(tr)
+        o = oracle.Problem(mission, AIRCRAFT[tr.aircraft], N=N, east_goal=tr.east_goal, north_goal=tr.north_goal,
+                           radius_goal=tr.radius_goal, start=(tr.xi, tr.yi, -40.0), Vref=tr.Vref, href=tr.href)
+        oprobs.append(o)
+        X.append(oracle.perturbed(o, 1000 + t))
+    bt.set_trajectories(trajs)
+    # x0 of the batch API agrees with the oracle's
+    assert np.array_equal(bt.x0(3, zi=-40.0), oprobs[3].x0())
+    X = np.stack(X)
+    dX, dF, dG = bt.alloc(B, pad=pad)
+    tdt = bt.torch_dtype()
+    dX[:, :bt.n] = torch.from_numpy(X).to(tdt).cuda()
+    dF.fill_(float("nan")); dG.fill_(float("nan"))
+    bt.eval(dX, dF, dG)
+    obj = bt.objectives(dF)
+    torch.cuda.synchronize()
+    F = dF[:, :bt.neF].double().cpu().numpy()
+    G = dG[:, :bt.neG].double().cpu().numpy()
+    # padding columns must not be written
+    if dF.shape[1] > bt.neF:
+        assert torch.isnan(dF[:, bt.neF:]).all()
+    if dG.shape[1] > bt.neG:
+        assert torch.isnan(dG[:, bt.neG:]).all()
+    Xin = dX[:, :bt.n].double().cpu().numpy()       # what the kernel really saw (rounded for f32)
+    tol = 1e-12 if dtype == "f64" else 2e-3
+    for t in range(B):
+        Fo, Go = oprobs[t].eval(Xin[t])
+        assert_close(F[t], Fo, tol=tol, what=f"batch {mission} {dtype} F[{t}]")
+        assert_close(G[t], Go, tol=tol, mask=oprobs[t].undefined_mask(), what=f"batch {mission} {dtype} G[{t}]")
+    assert_close(obj.double().cpu().numpy(), F[:, 0], tol=0.0, what="objectives gather")

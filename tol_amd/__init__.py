@@ -1,0 +1,11 @@
+"""tol_amd -- MI355X-native implementation of tol's SNOPT user-function path.
+
+The product is the C-ABI library tol_amd/lib/libtolfg.so (sources in tol_amd/csrc, interface in
+include/tolfg.h).  This package is the thin Python host layer over that ABI: ctypes bindings, device
+buffers through torch, and the one-process-per-GPU batch driver.  There is no CPU fallback: every
+evaluation needs a gfx950 device and raises TolfgError otherwise.
+"""
+from .capi import TolfgError, lib, lib_path   # noqa: F401
+from .host import Batch, Problem, Trajectory  # noqa: F401
+
+__all__ = ["Batch", "Problem", "Trajectory", "TolfgError", "lib", "lib_path"]

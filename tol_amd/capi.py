@@ -1,0 +1,153 @@
+"""ctypes declarations for include/tolfg.h."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+OK, ERR_ARG, ERR_PARAM, ERR_HIP, ERR_NOCURRENT = 0, -1, -2, -3, -4
+WIND_NONE, WIND_SHEAR, WIND_TABLE = 0, 1, 99
+F64, F32 = 0, 1
+IU_MAGIC = 0x70F6
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+
+
+class TolfgError(RuntimeError):
+    def __init__(self, code, text):
+        super().__init__(f"tolfg error {code}: {text}")
+        self.code = code
+
+
+class Config(C.Structure):
+    _fields_ = [("mission", C.c_char_p), ("aircraft", C.c_char_p), ("root_path", C.c_char_p),
+                ("east", C.c_double), ("north", C.c_double), ("up", C.c_double),
+                ("east_goal", C.c_double), ("north_goal", C.c_double), ("up_goal", C.c_double),
+                ("radius_goal", C.c_double),
+                ("ts", C.c_int), ("windmodel", C.c_int),
+                ("Vref", C.c_double), ("href", C.c_double),
+                ("xi", C.c_double), ("yi", C.c_double), ("zi", C.c_double),
+                ("device", C.c_int), ("debug_dumps", C.c_int)]
+
+
+class Traj(C.Structure):
+    _fields_ = [("aircraft", C.c_int), ("reserved", C.c_int),
+                ("Vref", C.c_double), ("href", C.c_double),
+                ("north_goal", C.c_double), ("east_goal", C.c_double), ("radius_goal", C.c_double),
+                ("xi", C.c_double), ("yi", C.c_double)]
+
+
+class BatchConfig(C.Structure):
+    _fields_ = [("mission", C.c_char_p), ("root_path", C.c_char_p),
+                ("aircraft", C.POINTER(C.c_char_p)), ("n_aircraft", C.c_int),
+                ("ts", C.c_int), ("windmodel", C.c_int), ("dtype", C.c_int), ("device", C.c_int)]
+
+
+# snFunA, include/snopt/snopt.h:60-66 of the reference
+SNFUNA = C.CFUNCTYPE(None, _ip, _ip, _dp, _ip, _ip, _dp, _ip, _ip, _dp, C.c_char_p, _ip, _ip, _ip, _dp, _ip)
+
+# every symbol include/tolfg.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "tolfg_last_error": (C.c_char_p, []),
+    "tolfg_version": (C.c_char_p, []),
+    "tolfg_default_root": (C.c_char_p, []),
+    "tolfg_read_params": (C.c_int, [C.c_char_p, _dp, C.c_int]),
+    "tolfg_config_default": (None, [C.POINTER(Config)]),
+    "tolfg_create": (C.c_int, [C.POINTER(Config), C.POINTER(C.c_void_p)]),
+    "tolfg_destroy": (None, [C.c_void_p]),
+    "tolfg_sizes": (C.c_int, [C.c_void_p, _ip, _ip, _ip]),
+    "tolfg_pattern": (C.c_int, [C.c_void_p, _ip, _ip]),
+    "tolfg_x0": (C.c_int, [C.c_void_p, _dp]),
+    "tolfg_bounds": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _dp]),
+    "tolfg_tolerances": (C.c_int, [C.c_void_p, _dp, _dp]),
+    "tolfg_set_wind_table": (C.c_int, [C.c_void_p, _dp]),
+    "tolfg_set_current": (None, [C.c_void_p]),
+    "tolfg_get_current": (C.c_void_p, []),
+    "tolfg_handle_index": (C.c_int, [C.c_void_p]),
+    "DEFINEGusrfg_": (None, [_ip, _ip, _dp, _ip, _ip, _dp, _ip, _ip, _dp, C.c_char_p, _ip, _ip, _ip, _dp, _ip]),
+    "tolfg_modelWind": (C.c_int, [C.c_void_p, _dp]),
+    "tolfg_computeF": (C.c_int, [C.c_void_p, _dp, _dp]),
+    "tolfg_computeG": (C.c_int, [C.c_void_p, _dp, _dp]),
+    "tolfg_batch_create": (C.c_int, [C.POINTER(BatchConfig), C.POINTER(C.c_void_p)]),
+    "tolfg_batch_destroy": (None, [C.c_void_p]),
+    "tolfg_batch_sizes": (C.c_int, [C.c_void_p, _ip, _ip, _ip]),
+    "tolfg_batch_pattern": (C.c_int, [C.c_void_p, _ip, _ip]),
+    "tolfg_batch_set_trajectories": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Traj)]),
+    "tolfg_batch_x0": (C.c_int, [C.c_void_p, C.c_int, C.c_double, _dp]),
+    "tolfg_batch_bounds": (C.c_int, [C.c_void_p, C.c_int, C.c_double, _dp, _dp, _dp, _dp]),
+    "tolfg_batch_eval": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_long, C.c_void_p, C.c_long,
+                                   C.c_void_p, C.c_long, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "tolfg_batch_objectives": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_long, C.c_void_p, C.c_void_p]),
+    "tolfg_batch_algorithmic_bytes": (C.c_double, [C.c_void_p, C.c_int]),
+}
+
+_lib = None
+_hip_runtime = None
+
+
+def lib_path():
+    return os.path.join(HERE, "lib", "libtolfg.so")
+
+
+def hip_runtime_path():
+    """The single HIP runtime this process uses.
+
+    A process may hold only ONE copy of libamdhip64: a second copy cannot open the GPU.  PyTorch
+    wheels bundle their own copy, so when torch is importable its copy is the one (torch is imported
+    first so that it is already mapped); otherwise the system runtime under /opt/rocm is used.
+    TOLFG_HIP_RUNTIME overrides both."""
+    env = os.environ.get("TOLFG_HIP_RUNTIME")
+    if env:
+        return env
+    try:
+        import torch
+        cand = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            return cand
+    except ImportError:
+        pass
+    for cand in ("/opt/rocm/lib/libamdhip64.so", "/opt/rocm/lib/libamdhip64.so.7"):
+        if os.path.exists(cand):
+            return cand
+    raise TolfgError(ERR_HIP, "no libamdhip64 found (set TOLFG_HIP_RUNTIME)")
+
+
+def mapped_hip_runtimes():
+    """Paths of every libamdhip64 currently mapped into this process (should be exactly one)."""
+    out = set()
+    try:
+        with open("/proc/self/maps") as fh:
+            for line in fh:
+                if "libamdhip64" in line:
+                    out.add(line.split()[-1])
+    except OSError:
+        pass
+    return sorted(out)
+
+
+def lib():
+    """Load libtolfg.so.  Fails loudly when it has not been built (no fallback path exists)."""
+    global _lib
+    if _lib is None:
+        path = lib_path()
+        if not os.path.exists(path):
+            raise TolfgError(ERR_HIP, f"{path} is missing: run `python -m tol_amd.build` (hipcc, gfx950)")
+        # libtolfg.so carries no DT_NEEDED for the HIP runtime (csrc/Makefile explains why): make the
+        # process-wide copy globally visible first, then load the library against it.
+        global _hip_runtime
+        _hip_runtime = C.CDLL(hip_runtime_path(), mode=C.RTLD_GLOBAL)
+        L = C.CDLL(path)
+        if len(mapped_hip_runtimes()) > 1:
+            raise TolfgError(ERR_HIP, "two HIP runtimes are mapped: %s" % mapped_hip_runtimes())
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != OK:
+        raise TolfgError(rc, lib().tolfg_last_error().decode())
+    return rc

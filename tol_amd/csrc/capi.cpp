@@ -1,0 +1,327 @@
+// capi.cpp -- the extern "C" surface declared in include/tolfg.h.  No exception leaves this file:
+// the SNOPT callback is entered from a Fortran frame (ref: f_snkera, src/snoptProblem.cpp:468).
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include <hip/hip_runtime_api.h>
+
+#include "../../include/tolfg.h"
+#include "problem.h"
+
+using namespace tolfg;
+
+struct tolfg_problem {
+    problem *p;
+    int index;
+};
+struct tolfg_batch {
+    batch *b;
+};
+
+namespace {
+
+thread_local std::string g_err;
+std::mutex g_reg_mu;
+std::vector<tolfg_problem *> g_registry;     // handle index -> problem, for the iu[] route
+tolfg_problem *g_current = nullptr;
+
+int fail(int code, const std::string &msg)
+{
+    g_err = msg;
+    return code;
+}
+
+template <typename Fn>
+int guarded(Fn &&fn)
+{
+    try {
+        g_err.clear();
+        fn();
+        return TOLFG_OK;
+    } catch (const std::length_error &e) {
+        return fail(TOLFG_ERR_PARAM, e.what());
+    } catch (const hip_failure &e) {
+        return fail(TOLFG_ERR_HIP, e.what());
+    } catch (const std::invalid_argument &e) {
+        return fail(TOLFG_ERR_ARG, e.what());
+    } catch (const std::out_of_range &e) {
+        return fail(TOLFG_ERR_ARG, e.what());
+    } catch (const std::bad_alloc &) {
+        return fail(TOLFG_ERR_HIP, "out of host memory");
+    } catch (const std::exception &e) {
+        return fail(TOLFG_ERR_HIP, e.what());
+    } catch (...) {
+        return fail(TOLFG_ERR_HIP, "unknown failure");
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *tolfg_last_error(void) { return g_err.c_str(); }
+const char *tolfg_version(void) { return "tolfg-mi355x 0.1 (gfx950)"; }
+
+const char *tolfg_default_root(void)
+{
+    static const std::string root = default_root();
+    return root.c_str();
+}
+
+int tolfg_read_params(const char *path, double *out, int maxn)
+{
+    if (!path || (maxn > 0 && !out)) return fail(TOLFG_ERR_ARG, "tolfg_read_params: null argument");
+    std::vector<double> v;
+    if (!readparams(path, v)) return fail(TOLFG_ERR_PARAM, std::string("cannot open ") + path);
+    for (int i = 0; i < maxn && i < (int)v.size(); ++i) out[i] = v[i];
+    return (int)v.size();
+}
+
+void tolfg_config_default(tolfg_config *cfg)
+{
+    if (!cfg) return;
+    std::memset(cfg, 0, sizeof(*cfg));
+    cfg->mission = "S10";
+    cfg->aircraft = "tempest";
+    cfg->root_path = nullptr;
+    cfg->windmodel = TOLFG_WIND_SHEAR;   // what the reference runs offline (src/problem.cpp:73-78)
+    cfg->Vref = 2.4;                     // src/problem.cpp:504
+    cfg->href = 10.0;                    // src/problem.cpp:505
+}
+
+int tolfg_create(const tolfg_config *cfg, tolfg_problem **out)
+{
+    if (!cfg || !out) return fail(TOLFG_ERR_ARG, "tolfg_create: null argument");
+    *out = nullptr;
+    return guarded([&] {
+        if (!cfg->mission) throw std::invalid_argument("mission is required");
+        problem *p = nullptr;
+        switch (mission_from_name(cfg->mission)) {      // ref: mission_select, src/tol.cpp:5-24
+        case MISSION_S10: p = new problemS10(*cfg); break;
+        case MISSION_G7:  p = new problemG7(*cfg); break;
+        }
+        tolfg_problem *h = new tolfg_problem{p, -1};
+        std::lock_guard<std::mutex> lk(g_reg_mu);
+        h->index = (int)g_registry.size();
+        g_registry.push_back(h);
+        *out = h;
+    });
+}
+
+void tolfg_destroy(tolfg_problem *h)
+{
+    if (!h) return;
+    {
+        std::lock_guard<std::mutex> lk(g_reg_mu);
+        if (h->index >= 0 && h->index < (int)g_registry.size()) g_registry[h->index] = nullptr;
+        if (g_current == h) g_current = nullptr;
+    }
+    delete h->p;
+    delete h;
+}
+
+int tolfg_sizes(const tolfg_problem *h, int *n, int *neF, int *neG)
+{
+    if (!h) return fail(TOLFG_ERR_ARG, "null problem");
+    if (n) *n = h->p->n;
+    if (neF) *neF = h->p->neF;
+    if (neG) *neG = h->p->neG;
+    return TOLFG_OK;
+}
+
+int tolfg_pattern(const tolfg_problem *h, int *iGfun, int *jGvar)
+{
+    if (!h || !iGfun || !jGvar) return fail(TOLFG_ERR_ARG, "null argument");
+    std::memcpy(iGfun, h->p->iGfun.data(), sizeof(int) * h->p->neG);
+    std::memcpy(jGvar, h->p->jGvar.data(), sizeof(int) * h->p->neG);
+    return TOLFG_OK;
+}
+
+int tolfg_x0(const tolfg_problem *h, double *x)
+{
+    if (!h || !x) return fail(TOLFG_ERR_ARG, "null argument");
+    std::memcpy(x, h->p->x.data(), sizeof(double) * h->p->n);
+    return TOLFG_OK;
+}
+
+int tolfg_bounds(const tolfg_problem *h, double *xlow, double *xupp, double *Flow, double *Fupp)
+{
+    if (!h) return fail(TOLFG_ERR_ARG, "null problem");
+    if (xlow) std::memcpy(xlow, h->p->xlow.data(), sizeof(double) * h->p->n);
+    if (xupp) std::memcpy(xupp, h->p->xupp.data(), sizeof(double) * h->p->n);
+    if (Flow) std::memcpy(Flow, h->p->Flow.data(), sizeof(double) * h->p->neF);
+    if (Fupp) std::memcpy(Fupp, h->p->Fupp.data(), sizeof(double) * h->p->neF);
+    return TOLFG_OK;
+}
+
+int tolfg_tolerances(const tolfg_problem *h, double *opt_tol, double *feas_tol)
+{
+    if (!h) return fail(TOLFG_ERR_ARG, "null problem");
+    if (opt_tol) *opt_tol = h->p->sn.opt_tol;
+    if (feas_tol) *feas_tol = h->p->sn.feas_tol;
+    return TOLFG_OK;
+}
+
+int tolfg_set_wind_table(tolfg_problem *h, const double *wind_enu)
+{
+    if (!h) return fail(TOLFG_ERR_ARG, "null problem");
+    return guarded([&] { h->p->set_wind_table(wind_enu); });
+}
+
+void tolfg_set_current(tolfg_problem *h)
+{
+    std::lock_guard<std::mutex> lk(g_reg_mu);
+    g_current = h;
+    prob = h ? h->p : nullptr;
+}
+
+tolfg_problem *tolfg_get_current(void) { return g_current; }
+
+int tolfg_handle_index(const tolfg_problem *h) { return h ? h->index : -1; }
+
+void DEFINEGusrfg_(int *Status, int *n, double x[], int *needF, int *neF, double F[], int *needG, int *neG,
+                   double G[], char *cu, int *lencu, int iu[], int *leniu, double ru[], int *lenru)
+{
+    (void)cu; (void)lencu; (void)ru; (void)lenru;
+    problem *p = prob;
+    if (iu && leniu && *leniu >= 2 && iu[0] == TOLFG_IU_MAGIC) {
+        std::lock_guard<std::mutex> lk(g_reg_mu);
+        const int idx = iu[1];
+        p = (idx >= 0 && idx < (int)g_registry.size() && g_registry[idx]) ? g_registry[idx]->p : nullptr;
+    }
+    const bool wantF = needF && *needF > 0, wantG = needG && *needG > 0;
+    int rc;
+    if (!p) {
+        rc = fail(TOLFG_ERR_NOCURRENT, "DEFINEGusrfg_: no current problem (call tolfg_set_current)");
+    } else if (!n || !x || *n != p->n || (wantF && (!neF || !F || *neF != p->neF)) ||
+               (wantG && (!neG || !G || *neG != p->neG))) {
+        rc = fail(TOLFG_ERR_ARG, "DEFINEGusrfg_: array sizes do not match the current problem");
+    } else {
+        rc = guarded([&] { p->evaluate(x, wantF, F, wantG, G); });
+    }
+    if (rc != TOLFG_OK) {
+        std::fprintf(stderr, "tolfg: %s\n", g_err.c_str());
+        if (Status) *Status = -2;   // snOptA: a value <= -2 asks SNOPT to terminate
+    }
+}
+
+int tolfg_modelWind(tolfg_problem *h, const double *x)
+{
+    if (!h || !x) return fail(TOLFG_ERR_ARG, "null argument");
+    return guarded([&] { h->p->modelWind(x); });
+}
+
+int tolfg_computeF(tolfg_problem *h, const double *x, double *F)
+{
+    if (!h || !x || !F) return fail(TOLFG_ERR_ARG, "null argument");
+    return guarded([&] { h->p->computeF(x, F); });
+}
+
+int tolfg_computeG(tolfg_problem *h, const double *x, double *G)
+{
+    if (!h || !x || !G) return fail(TOLFG_ERR_ARG, "null argument");
+    return guarded([&] { h->p->computeG(x, G); });
+}
+
+// ------------------------------------------------------------------------------------ batch
+
+int tolfg_batch_create(const tolfg_batch_config *cfg, tolfg_batch **out)
+{
+    if (!cfg || !out) return fail(TOLFG_ERR_ARG, "tolfg_batch_create: null argument");
+    *out = nullptr;
+    return guarded([&] {
+        if (!cfg->mission || !cfg->aircraft || cfg->n_aircraft < 1)
+            throw std::invalid_argument("mission and at least one aircraft are required");
+        std::vector<std::string> names;
+        for (int i = 0; i < cfg->n_aircraft; ++i) {
+            if (!cfg->aircraft[i]) throw std::invalid_argument("null aircraft name");
+            names.emplace_back(cfg->aircraft[i]);
+        }
+        const std::string root = cfg->root_path ? std::string(cfg->root_path) : default_root();
+        *out = new tolfg_batch{new batch(cfg->mission, root, names, cfg->ts, cfg->windmodel, cfg->dtype, cfg->device)};
+    });
+}
+
+void tolfg_batch_destroy(tolfg_batch *h)
+{
+    if (!h) return;
+    delete h->b;
+    delete h;
+}
+
+int tolfg_batch_sizes(const tolfg_batch *h, int *n, int *neF, int *neG)
+{
+    if (!h) return fail(TOLFG_ERR_ARG, "null batch");
+    const Sizes &s = h->b->sizes();
+    if (n) *n = s.n;
+    if (neF) *neF = s.neF;
+    if (neG) *neG = s.neG;
+    return TOLFG_OK;
+}
+
+int tolfg_batch_pattern(const tolfg_batch *h, int *iGfun, int *jGvar)
+{
+    if (!h || !iGfun || !jGvar) return fail(TOLFG_ERR_ARG, "null argument");
+    make_pattern(h->b->sizes(), iGfun, jGvar);
+    return TOLFG_OK;
+}
+
+int tolfg_batch_set_trajectories(tolfg_batch *h, int B, const tolfg_traj *trajs)
+{
+    if (!h) return fail(TOLFG_ERR_ARG, "null batch");
+    return guarded([&] { h->b->set_trajectories(B, trajs); });
+}
+
+int tolfg_batch_x0(const tolfg_batch *h, int t, double zi, double *x)
+{
+    if (!h || !x) return fail(TOLFG_ERR_ARG, "null argument");
+    return guarded([&] {
+        const tolfg_traj &tr = h->b->trajectory(t);
+        initial_guess(h->b->sizes(), h->b->airframe(tr.aircraft), Start{tr.xi, tr.yi, zi}, h->b->chi_d(t), x);
+    });
+}
+
+int tolfg_batch_bounds(const tolfg_batch *h, int t, double zi, double *xlow, double *xupp, double *Flow,
+                       double *Fupp)
+{
+    if (!h) return fail(TOLFG_ERR_ARG, "null batch");
+    return guarded([&] {
+        const Sizes &s = h->b->sizes();
+        const tolfg_traj &tr = h->b->trajectory(t);
+        std::vector<double> xl(s.n), xu(s.n), Fl(s.neF), Fu(s.neF);
+        set_limits(s, h->b->airframe(tr.aircraft), h->b->limits(), Start{tr.xi, tr.yi, zi}, xl.data(), xu.data(),
+                   Fl.data(), Fu.data());
+        if (xlow) std::memcpy(xlow, xl.data(), sizeof(double) * s.n);
+        if (xupp) std::memcpy(xupp, xu.data(), sizeof(double) * s.n);
+        if (Flow) std::memcpy(Flow, Fl.data(), sizeof(double) * s.neF);
+        if (Fupp) std::memcpy(Fupp, Fu.data(), sizeof(double) * s.neF);
+    });
+}
+
+int tolfg_batch_eval(tolfg_batch *h, int B, const void *dX, long ldx, void *dF, long ldf, void *dG, long ldg,
+                     const void *dWind, int needF, int needG, void *stream)
+{
+    if (!h) return fail(TOLFG_ERR_ARG, "null batch");
+    return guarded([&] {
+        h->b->eval(B, dX, ldx, dF, ldf, dG, ldg, dWind, needF, needG, static_cast<hipStream_t>(stream));
+    });
+}
+
+int tolfg_batch_objectives(tolfg_batch *h, int B, const void *dF, long ldf, void *dObj, void *stream)
+{
+    if (!h) return fail(TOLFG_ERR_ARG, "null batch");
+    return guarded([&] { h->b->objectives(B, dF, ldf, dObj, static_cast<hipStream_t>(stream)); });
+}
+
+double tolfg_batch_algorithmic_bytes(const tolfg_batch *h, int B)
+{
+    if (!h) return 0.0;
+    const Sizes &s = h->b->sizes();
+    return (double)h->b->elem_size() * (double)B * ((double)s.n + s.neF + s.neG);
+}
+
+}  // extern "C"

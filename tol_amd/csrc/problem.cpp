@@ -1,0 +1,309 @@
+// problem.cpp -- host side: batched evaluator and the SNOPT-facing problem objects.
+#include "problem.h"
+
+#include <dlfcn.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+
+#include <hip/hip_runtime_api.h>
+
+namespace tolfg {
+
+problem *prob = nullptr;
+
+namespace {
+
+constexpr double kRho = 1.2682;   // ref: include/problem.h:73
+
+void check(hipError_t e, const char *what)
+{
+    if (e != hipSuccess)
+        throw hip_failure(std::string(what) + ": " + hipGetErrorString(e));
+}
+
+int kernel_wind(int windmodel)
+{
+    switch (windmodel) {
+    case TOLFG_WIND_NONE:  return WIND_NONE;
+    case TOLFG_WIND_SHEAR: return WIND_SHEAR;
+    case TOLFG_WIND_TABLE: return WIND_TABLE;
+    }
+    throw std::invalid_argument("unknown wind model");
+}
+
+}  // namespace
+
+int mission_from_name(const std::string &name)
+{
+    if (name == "S10") return MISSION_S10;
+    if (name == "G7") return MISSION_G7;
+    throw std::invalid_argument("Mission code \"" + name + "\" not recognized.");   // ref: src/tol.cpp:21
+}
+
+std::string default_root()
+{
+    // <repo>/tol_amd/lib/libtolfg.so -> <repo>/tol_amd/data/
+    Dl_info info;
+    if (dladdr(reinterpret_cast<const void *>(&default_root), &info) && info.dli_fname) {
+        std::string p(info.dli_fname);
+        const size_t a = p.find_last_of('/');
+        if (a != std::string::npos) {
+            p.erase(a);
+            const size_t b = p.find_last_of('/');
+            if (b != std::string::npos) return p.substr(0, b) + "/data/";
+        }
+    }
+    return "./";   // the reference's command-line root_path (src/arguments.cpp:45)
+}
+
+// ------------------------------------------------------------------------------------ batch
+
+batch::batch(const std::string &mission, const std::string &root, const std::vector<std::string> &names,
+             int ts, int windmodel, int dtype, int device)
+    : gn_(mission, root), lm_(mission, root), sn_(mission, root), windmodel_(windmodel), dtype_(dtype),
+      device_(device)
+{
+    const int mid = mission_from_name(mission);
+    if (names.empty() || names.size() > MAX_AIRCRAFT) throw std::invalid_argument("1..8 aircraft per batch");
+    if (dtype != TOLFG_F64 && dtype != TOLFG_F32) throw std::invalid_argument("dtype");
+    kernel_wind(windmodel);
+    for (const std::string &nm : names) acs_.emplace_back(nm, root);
+    const int N = ts > 0 ? ts : sn_.ts;
+    if (N < 1) throw std::invalid_argument("ts must be >= 1");
+    if (sn_.numinp != 11 || sn_.numstates != 8 || sn_.numbounds != (mid == MISSION_S10 ? 11 : 12))
+        throw std::invalid_argument("snopt.param: numinp/numstates/numbounds do not describe " + mission);
+    sz_ = make_sizes(mid, N);
+
+    args_.N = N;
+    args_.tiles = (N + 63) / 64;
+    args_.c0 = sz_.c0;
+    args_.kT = gn_.kT; args_.kp = gn_.kp; args_.kv = gn_.kv; args_.kdt = gn_.kdt;
+    for (size_t i = 0; i < acs_.size(); ++i) {
+        const aircraft &a = acs_[i];
+        args_.ac[i].inv_m = 1.0 / a.mm;
+        args_.ac[i].qk = kRho * a.SS / (2.0 * a.mm);
+        args_.ac[i].Cd0 = a.Cd0;
+        args_.ac[i].kind = 1.0 / (a.AR * M_PI * a.ee);
+    }
+}
+
+batch::~batch()
+{
+    if (d_traj_) (void)hipFree(d_traj_);
+}
+
+double batch::chi_d(int t) const
+{
+    const tolfg_traj &tr = host_traj_.at(t);
+    return std::atan2(tr.east_goal - tr.yi, tr.north_goal - tr.xi);   // ref: src/problemG7.cpp:524
+}
+
+void batch::set_trajectories(int B, const tolfg_traj *trajs)
+{
+    if (B < 1 || !trajs) throw std::invalid_argument("set_trajectories: B >= 1 and a table are required");
+    std::vector<TrajDev> dev(B);
+    for (int t = 0; t < B; ++t) {
+        const tolfg_traj &tr = trajs[t];
+        if (tr.aircraft < 0 || tr.aircraft >= (int)acs_.size()) throw std::invalid_argument("aircraft index");
+        TrajDev &d = dev[t];
+        d.shear = tr.Vref / tr.href;
+        d.xg = tr.north_goal; d.yg = tr.east_goal; d.rg = tr.radius_goal;   // ENU -> NED
+        const double cd = std::atan2(tr.east_goal - tr.yi, tr.north_goal - tr.xi);
+        d.cchi = std::cos(cd); d.schi = std::sin(cd);
+        d.ac = tr.aircraft; d.pad = 0;
+    }
+    host_traj_.assign(trajs, trajs + B);
+    dev_traj_.swap(dev);
+    ntraj_ = B;
+    uploaded_ = false;     // the device copy is made by the first eval (set-up needs no GPU)
+}
+
+void batch::upload()
+{
+    check(hipSetDevice(device_), "hipSetDevice");
+    if (ntraj_ > cap_) {
+        if (d_traj_) check(hipFree(d_traj_), "hipFree");
+        d_traj_ = nullptr;
+        check(hipMalloc(reinterpret_cast<void **>(&d_traj_), sizeof(TrajDev) * (size_t)ntraj_), "hipMalloc(traj)");
+        cap_ = ntraj_;
+    }
+    check(hipMemcpy(d_traj_, dev_traj_.data(), sizeof(TrajDev) * (size_t)ntraj_, hipMemcpyHostToDevice),
+          "hipMemcpy(traj)");
+    uploaded_ = true;
+}
+
+void batch::eval(int B, const void *dX, long ldx, void *dF, long ldf, void *dG, long ldg, const void *dWind,
+                 int needF, int needG, hipStream_t stream)
+{
+    if (B < 1 || B > ntraj_) throw std::invalid_argument("eval: B exceeds the described trajectories");
+    if (!dX || (needF && !dF) || (needG && !dG)) throw std::invalid_argument("eval: null device pointer");
+    if (ldx < sz_.n || (needF && ldf < sz_.neF) || (needG && ldg < sz_.neG))
+        throw std::invalid_argument("eval: leading dimension smaller than the row");
+    if (windmodel_ == TOLFG_WIND_TABLE && !dWind) throw std::invalid_argument("eval: table wind needs dWind");
+    if (!uploaded_) upload();
+    FgArgs a = args_;
+    a.X = dX; a.ldx = ldx; a.F = dF; a.ldf = ldf; a.G = dG; a.ldg = ldg;
+    a.wind = dWind; a.traj = d_traj_;
+    a.B = B; a.needF = needF ? 1 : 0; a.needG = needG ? 1 : 0;
+    // 16-byte accesses need every row's x window and slab region on a 16-byte boundary
+    const int vmax = dtype_ == TOLFG_F64 ? 2 : 4;
+    const bool aligned = (reinterpret_cast<uintptr_t>(dX) % 16 == 0) && (ldx % vmax == 0) &&
+                         (!needG || ((reinterpret_cast<uintptr_t>(dG) % 16 == 0) && (ldg % vmax == 0) &&
+                                     (sz_.c0 % vmax == 0)));
+    check(launch_fg(a, sz_.mission, kernel_wind(windmodel_), dtype_, aligned ? vmax : 1, stream), "launch fg");
+}
+
+void batch::objectives(int B, const void *dF, long ldf, void *dObj, hipStream_t stream)
+{
+    if (!dF || !dObj || B < 1) throw std::invalid_argument("objectives: bad arguments");
+    check(launch_objectives(dF, ldf, dObj, B, dtype_, stream), "launch objectives");
+}
+
+// ------------------------------------------------------------------------------------ problem
+
+namespace {
+std::string root_of(const tolfg_config &cfg) { return cfg.root_path ? std::string(cfg.root_path) : default_root(); }
+long even(long v) { return (v + 1) & ~1L; }
+batch *make_engine(const tolfg_config &cfg)
+{
+    if (!cfg.mission || !cfg.aircraft) throw std::invalid_argument("mission and aircraft are required");
+    return new batch(cfg.mission, root_of(cfg), {cfg.aircraft}, cfg.ts, cfg.windmodel, TOLFG_F64, cfg.device);
+}
+}  // namespace
+
+problem::problem(const tolfg_config &cfg, int mission_id)
+    : eng_(make_engine(cfg)), debug(cfg.debug_dumps != 0), ac(eng_->airframe(0)), gn(eng_->gains()),
+      lm(eng_->limits()), sn(eng_->snopt_params())
+{
+    const Sizes &sz = eng_->sizes();
+    if (sz.mission != mission_id) throw std::invalid_argument("mission mismatch");
+    n = sz.n; neF = sz.neF; neG = sz.neG;
+    east = cfg.east; north = cfg.north; up = cfg.up;
+    // goals ENU -> NED (ref: src/problem.cpp:24-27)
+    yg = cfg.east_goal; xg = cfg.north_goal; zg = -cfg.up_goal; rg = cfg.radius_goal;
+    mission = cfg.mission; aircraft_type = cfg.aircraft;
+
+    tolfg_traj tr{};
+    tr.aircraft = 0;
+    tr.Vref = cfg.Vref; tr.href = cfg.href;
+    tr.north_goal = cfg.north_goal; tr.east_goal = cfg.east_goal; tr.radius_goal = cfg.radius_goal;
+    tr.xi = cfg.xi; tr.yi = cfg.yi;
+    eng_->set_trajectories(1, &tr);
+
+    iGfun.resize(neG); jGvar.resize(neG);
+    make_pattern(sz, iGfun.data(), jGvar.data());
+    x.resize(n); xlow.resize(n); xupp.resize(n); Flow.resize(neF); Fupp.resize(neF);
+    const Start st{cfg.xi, cfg.yi, cfg.zi};
+    initial_guess(sz, ac, st, eng_->chi_d(0), x.data());
+    set_limits(sz, ac, lm, st, xlow.data(), xupp.data(), Flow.data(), Fupp.data());
+
+    ldx_ = even(n); ldf_ = even(neF); ldg_ = even(neG);
+}
+
+void problem::ensure_device()
+{
+    // Device state is created by the first evaluation so that set-up (sizes, pattern, x0, bounds)
+    // also works on a host without a GPU; evaluation itself has no CPU path.
+    if (device_ready_) return;
+    check(hipSetDevice(eng_->device()), "hipSetDevice");
+    if (!stream_) check(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking), "hipStreamCreate");
+    if (!hx_) check(hipHostMalloc(reinterpret_cast<void **>(&hx_), sizeof(double) * ldx_, hipHostMallocDefault), "hipHostMalloc");
+    if (!hF_) check(hipHostMalloc(reinterpret_cast<void **>(&hF_), sizeof(double) * ldf_, hipHostMallocDefault), "hipHostMalloc");
+    if (!hG_) check(hipHostMalloc(reinterpret_cast<void **>(&hG_), sizeof(double) * ldg_, hipHostMallocDefault), "hipHostMalloc");
+    if (!dX_) check(hipMalloc(reinterpret_cast<void **>(&dX_), sizeof(double) * ldx_), "hipMalloc");
+    if (!dF_) check(hipMalloc(reinterpret_cast<void **>(&dF_), sizeof(double) * ldf_), "hipMalloc");
+    if (!dG_) check(hipMalloc(reinterpret_cast<void **>(&dG_), sizeof(double) * ldg_), "hipMalloc");
+    device_ready_ = true;
+}
+
+problem::~problem()
+{
+    if (prob == this) prob = nullptr;
+    if (stream_) (void)hipStreamSynchronize(stream_);
+    if (hx_) (void)hipHostFree(hx_);
+    if (hF_) (void)hipHostFree(hF_);
+    if (hG_) (void)hipHostFree(hG_);
+    if (dX_) (void)hipFree(dX_);
+    if (dF_) (void)hipFree(dF_);
+    if (dG_) (void)hipFree(dG_);
+    if (dW_) (void)hipFree(dW_);
+    if (stream_) (void)hipStreamDestroy(stream_);
+}
+
+void problem::set_wind_table(const double *wind_enu)
+{
+    if (!wind_enu) throw std::invalid_argument("wind table is null");
+    ensure_device();
+    const size_t bytes = sizeof(double) * 12 * (size_t)(eng_->sizes().N + 1);
+    check(hipSetDevice(eng_->device()), "hipSetDevice");
+    if (!dW_) check(hipMalloc(reinterpret_cast<void **>(&dW_), bytes), "hipMalloc(wind)");
+    check(hipMemcpy(dW_, wind_enu, bytes, hipMemcpyHostToDevice), "hipMemcpy(wind)");
+    eng_->set_windmodel(TOLFG_WIND_TABLE);
+    staged_ = false;
+}
+
+void problem::stage_and_launch(const double xin[], bool needF, bool needG)
+{
+    ensure_device();
+    check(hipSetDevice(eng_->device()), "hipSetDevice");
+    std::memcpy(hx_, xin, sizeof(double) * n);
+    check(hipMemcpyAsync(dX_, hx_, sizeof(double) * n, hipMemcpyHostToDevice, stream_), "H2D x");
+    eng_->eval(1, dX_, ldx_, dF_, ldf_, dG_, ldg_, dW_, needF, needG, stream_);
+    if (needF) check(hipMemcpyAsync(hF_, dF_, sizeof(double) * neF, hipMemcpyDeviceToHost, stream_), "D2H F");
+    if (needG) check(hipMemcpyAsync(hG_, dG_, sizeof(double) * neG, hipMemcpyDeviceToHost, stream_), "D2H G");
+    staged_ = true; haveF_ = needF; haveG_ = needG;
+}
+
+void problem::collect(bool wantF, double F[], bool wantG, double G[])
+{
+    check(hipStreamSynchronize(stream_), "stream sync");
+    if (wantF) std::memcpy(F, hF_, sizeof(double) * neF);
+    if (wantG) std::memcpy(G, hG_, sizeof(double) * neG);
+}
+
+void problem::dump(const char *name, const double *v, int len)
+{
+    // ref: src/DefineFG.cpp:16-21,29-34,41-46 -- same file names and "%.14f" format, opt-in here
+    if (FILE *fp = std::fopen(name, "w")) {
+        for (int i = 0; i < len; ++i) std::fprintf(fp, "%.14f\n", v[i]);
+        std::fclose(fp);
+    }
+}
+
+void problem::evaluate(const double xin[], bool needF, double F[], bool needG, double G[])
+{
+    if (debug) dump("Xoutput.txt", xin, n);
+    if (!needF && !needG) return;
+    stage_and_launch(xin, needF, needG);
+    collect(needF, F, needG, G);
+    if (debug && needF) dump("Foutput.txt", F, neF);
+    if (debug && needG) dump("Goutput.txt", G, neG);
+}
+
+void problem::modelWind(const double xin[])
+{
+    stage_and_launch(xin, true, true);
+}
+
+void problem::computeF(const double xin[], double F[])
+{
+    if (!staged_ || !haveF_ || std::memcmp(hx_, xin, sizeof(double) * n) != 0) stage_and_launch(xin, true, false);
+    collect(true, F, false, nullptr);
+}
+
+void problem::computeG(const double xin[], double G[])
+{
+    if (!staged_ || !haveG_ || std::memcmp(hx_, xin, sizeof(double) * n) != 0) stage_and_launch(xin, false, true);
+    collect(false, nullptr, true, G);
+}
+
+problemS10::problemS10(const tolfg_config &cfg) : problem(cfg, MISSION_S10) {}
+
+problemG7::problemG7(const tolfg_config &cfg)
+    : problem(cfg, MISSION_G7), chi_d(std::atan2(cfg.east_goal - cfg.yi, cfg.north_goal - cfg.xi))
+{
+}
+
+}  // namespace tolfg

@@ -1,0 +1,145 @@
+// problem.h -- host side of the user-function path: GPU-backed counterparts of the reference's
+// `problem` / `problemS10` / `problemG7` (ref: include/problem.h, include/problemS10.h,
+// include/problemG7.h) and a batched evaluator with no reference counterpart.
+#ifndef TOLFG_PROBLEM_H_
+#define TOLFG_PROBLEM_H_
+
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/tolfg.h"
+#include "kernels.h"
+#include "params.h"
+#include "setup.h"
+
+namespace tolfg {
+
+struct hip_failure : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+
+int mission_from_name(const std::string &name);   // throws std::invalid_argument (ref: src/tol.cpp:19-23)
+std::string default_root();
+
+// ---------------------------------------------------------------------------------------------
+// Device-resident evaluation of B independent trajectories that share mission and ts.
+class batch {
+public:
+    batch(const std::string &mission, const std::string &root, const std::vector<std::string> &aircraft_names,
+          int ts, int windmodel, int dtype, int device);
+    ~batch();
+    batch(const batch &) = delete;
+    batch &operator=(const batch &) = delete;
+
+    const Sizes &sizes() const { return sz_; }
+    int dtype() const { return dtype_; }
+    int device() const { return device_; }
+    int windmodel() const { return windmodel_; }
+    void set_windmodel(int wm) { windmodel_ = wm; }
+    size_t elem_size() const { return dtype_ == TOLFG_F64 ? 8 : 4; }
+    const aircraft &airframe(int i) const { return acs_.at(i); }
+    const gain &gains() const { return gn_; }
+    const limit &limits() const { return lm_; }
+    const snopt &snopt_params() const { return sn_; }
+
+    void set_trajectories(int B, const tolfg_traj *trajs);
+    int trajectories() const { return ntraj_; }
+    const tolfg_traj &trajectory(int t) const { return host_traj_.at(t); }
+    double chi_d(int t) const;
+
+    // asynchronous on `stream`
+    void eval(int B, const void *dX, long ldx, void *dF, long ldf, void *dG, long ldg, const void *dWind,
+              int needF, int needG, hipStream_t stream);
+    void objectives(int B, const void *dF, long ldf, void *dObj, hipStream_t stream);
+
+private:
+    Sizes sz_;
+    std::vector<aircraft> acs_;
+    gain gn_;
+    limit lm_;
+    snopt sn_;
+    int windmodel_, dtype_, device_;
+    void upload();
+    int ntraj_ = 0, cap_ = 0;
+    bool uploaded_ = false;
+    TrajDev *d_traj_ = nullptr;
+    std::vector<tolfg_traj> host_traj_;
+    std::vector<TrajDev> dev_traj_;
+    FgArgs args_{};
+};
+
+// ---------------------------------------------------------------------------------------------
+// ref: class problem, include/problem.h:17-140.  Public surface kept: modelWind / computeF /
+// computeG (what DEFINEGusrfg_ calls, src/DefineFG.cpp:24-37) and the SNOPT companion data; the
+// members the reference exposes to its missions keep their names (ac, gn, lm, sn, n, neF, neG,
+// iGfun, jGvar, x, xlow, xupp, Flow, Fupp, xg, yg, rg).
+class problem {
+    std::unique_ptr<batch> eng_;      // declared first: the parameter references below bind to it
+public:
+    virtual ~problem();
+    problem(const problem &) = delete;
+    problem &operator=(const problem &) = delete;
+
+    // ref: problem::modelWind(x), src/problem.cpp:475.  Wind models 0/1 are fused into the kernel,
+    // so this stages x on the device and starts the evaluation; computeF/computeG collect.
+    void modelWind(const double x[]);
+    // ref: problem::computeF(x, F), src/problem.cpp:765
+    void computeF(const double x[], double F[]);
+    // ref: problem::computeG(x, G), src/problem.cpp:782
+    void computeG(const double x[], double G[]);
+    // what DEFINEGusrfg_ uses: one launch, only the requested outputs come back
+    void evaluate(const double x[], bool needF, double F[], bool needG, double G[]);
+
+    void set_wind_table(const double *wind_enu);   // [12][ts+1], ENU, reference member order
+
+    bool debug;                       // ref: problem::debug, include/problem.h:26 (default false here)
+
+    // SNOPT companion data (ref: include/problem.h:109-136)
+    int n, neF, neG;
+    std::vector<int> iGfun, jGvar;
+    std::vector<double> x, xlow, xupp, Flow, Fupp;
+    int ObjRow = 0;
+    double ObjAdd = 0;
+    int neA = 0;
+    const aircraft &ac;
+    const gain &gn;
+    const limit &lm;
+    const snopt &sn;
+    double xg, yg, zg, rg;            // goal, NED (ref: src/problem.cpp:24-27)
+    double east, north, up;
+    std::string mission, aircraft_type;
+
+protected:
+    problem(const tolfg_config &cfg, int mission_id);
+
+private:
+    void ensure_device();
+    void stage_and_launch(const double x[], bool needF, bool needG);
+    void collect(bool wantF, double F[], bool wantG, double G[]);
+    void dump(const char *name, const double *v, int len);
+
+    hipStream_t stream_ = nullptr;
+    double *hx_ = nullptr, *hF_ = nullptr, *hG_ = nullptr;      // pinned
+    double *dX_ = nullptr, *dF_ = nullptr, *dG_ = nullptr, *dW_ = nullptr;
+    long ldx_, ldf_, ldg_;
+    bool device_ready_ = false, staged_ = false, haveF_ = false, haveG_ = false;
+};
+
+// ref: class problemS10 / problemG7 -- the two missions on the path
+class problemS10 : public problem {
+public:
+    explicit problemS10(const tolfg_config &cfg);
+};
+class problemG7 : public problem {
+public:
+    explicit problemG7(const tolfg_config &cfg);
+    double chi_d;                     // ref: include/problemG7.h:23
+};
+
+// ref: `problem *prob`, src/tol.cpp:3 -- the context the SNOPT callback evaluates
+extern problem *prob;
+
+}  // namespace tolfg
+#endif

@@ -1,0 +1,259 @@
+"""Python host layer over the C ABI of libtolfg.so (include/tolfg.h).
+
+`Problem` is one SNOPT problem instance as the reference builds it in mission_select
+(ref: src/tol.cpp:5-24): sizes, pattern, x0, bounds and the DEFINEGusrfg_ callback.
+`Batch` is the device-resident evaluator for many independent trajectories (no reference
+counterpart); its buffers are torch CUDA tensors, torch being used only for device memory and streams.
+"""
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import capi
+from .capi import Config, BatchConfig, Traj, check, lib
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+
+
+def _d(a):
+    return a.ctypes.data_as(_dp)
+
+
+def _i(a):
+    return a.ctypes.data_as(_ip)
+
+
+def _enc(s):
+    return None if s is None else str(s).encode()
+
+
+class Problem:
+    """ref: `new problemS10(args)` / `new problemG7(args)` + what runSNOPT hands to SNOPT."""
+
+    def __init__(self, mission, aircraft="tempest", east=0.0, north=0.0, up=100.0, east_goal=400.0,
+                 north_goal=0.0, up_goal=70.0, radius_goal=100.0, ts=0, windmodel=capi.WIND_SHEAR,
+                 Vref=2.4, href=10.0, start=(0.0, 0.0, 0.0), device=0, root_path=None, debug_dumps=False):
+        L = lib()
+        cfg = Config()
+        L.tolfg_config_default(C.byref(cfg))
+        self._keep = (_enc(mission), _enc(aircraft), _enc(root_path))
+        cfg.mission, cfg.aircraft, cfg.root_path = self._keep
+        cfg.east, cfg.north, cfg.up = east, north, up
+        cfg.east_goal, cfg.north_goal, cfg.up_goal, cfg.radius_goal = east_goal, north_goal, up_goal, radius_goal
+        cfg.ts, cfg.windmodel, cfg.Vref, cfg.href = int(ts), int(windmodel), Vref, href
+        cfg.xi, cfg.yi, cfg.zi = start
+        cfg.device, cfg.debug_dumps = int(device), int(bool(debug_dumps))
+        self._h = C.c_void_p()
+        check(L.tolfg_create(C.byref(cfg), C.byref(self._h)))
+        n, neF, neG = C.c_int(), C.c_int(), C.c_int()
+        check(L.tolfg_sizes(self._h, C.byref(n), C.byref(neF), C.byref(neG)))
+        self.n, self.neF, self.neG = n.value, neF.value, neG.value
+        self.mission = mission
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().tolfg_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # ---- companion data for the SNOPT driver
+    def pattern(self):
+        iG = np.zeros(self.neG, dtype=np.int32)
+        jG = np.zeros(self.neG, dtype=np.int32)
+        check(lib().tolfg_pattern(self._h, _i(iG), _i(jG)))
+        return iG, jG
+
+    def x0(self):
+        x = np.zeros(self.n)
+        check(lib().tolfg_x0(self._h, _d(x)))
+        return x
+
+    def bounds(self):
+        xl, xu = np.zeros(self.n), np.zeros(self.n)
+        Fl, Fu = np.zeros(self.neF), np.zeros(self.neF)
+        check(lib().tolfg_bounds(self._h, _d(xl), _d(xu), _d(Fl), _d(Fu)))
+        return xl, xu, Fl, Fu
+
+    def tolerances(self):
+        a, b = C.c_double(), C.c_double()
+        check(lib().tolfg_tolerances(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def set_wind_table(self, wind_enu):
+        w = np.ascontiguousarray(wind_enu, dtype=np.float64)
+        check(lib().tolfg_set_wind_table(self._h, _d(w)))
+
+    # ---- the callback, exactly as SNOPT enters it
+    def make_current(self):
+        lib().tolfg_set_current(self._h)
+
+    def handle_index(self):
+        return lib().tolfg_handle_index(self._h)
+
+    def define_fg(self, x, needF=True, needG=True, status=1, use_iu=False):
+        """Call DEFINEGusrfg_ with snOptA's argument convention; returns (F, G, Status)."""
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        F, G = np.zeros(self.neF), np.zeros(self.neG)
+        st, n, neF, neG = C.c_int(status), C.c_int(len(x)), C.c_int(self.neF), C.c_int(self.neG)
+        nf, ng = C.c_int(int(needF)), C.c_int(int(needG))
+        zero = C.c_int(0)
+        if use_iu:
+            iu = (C.c_int * 2)(capi.IU_MAGIC, self.handle_index())
+            leniu = C.c_int(2)
+            lib().DEFINEGusrfg_(C.byref(st), C.byref(n), _d(x), C.byref(nf), C.byref(neF), _d(F), C.byref(ng),
+                                C.byref(neG), _d(G), None, C.byref(zero), iu, C.byref(leniu), None, C.byref(zero))
+        else:
+            self.make_current()
+            lib().DEFINEGusrfg_(C.byref(st), C.byref(n), _d(x), C.byref(nf), C.byref(neF), _d(F), C.byref(ng),
+                                C.byref(neG), _d(G), None, C.byref(zero), None, C.byref(zero), None, C.byref(zero))
+        return F, G, st.value
+
+    # ---- the three methods the reference's callback dispatches to
+    def modelWind(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        check(lib().tolfg_modelWind(self._h, _d(x)))
+
+    def computeF(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        F = np.zeros(self.neF)
+        check(lib().tolfg_computeF(self._h, _d(x), _d(F)))
+        return F
+
+    def computeG(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        G = np.zeros(self.neG)
+        check(lib().tolfg_computeG(self._h, _d(x), _d(G)))
+        return G
+
+
+@dataclass
+class Trajectory:
+    aircraft: int = 0
+    Vref: float = 2.4
+    href: float = 10.0
+    north_goal: float = 0.0
+    east_goal: float = 400.0
+    radius_goal: float = 100.0
+    xi: float = 0.0
+    yi: float = 0.0
+
+
+class Batch:
+    """Device-resident evaluation of B trajectories that share mission and ts (one GPU)."""
+
+    def __init__(self, mission, aircraft=("tempest",), ts=0, windmodel=capi.WIND_SHEAR, dtype="f64",
+                 device=0, root_path=None):
+        L = lib()
+        names = [a.encode() for a in aircraft]
+        arr = (C.c_char_p * len(names))(*names)
+        cfg = BatchConfig()
+        self._keep = (_enc(mission), _enc(root_path), arr, names)
+        cfg.mission, cfg.root_path = self._keep[0], self._keep[1]
+        cfg.aircraft, cfg.n_aircraft = arr, len(names)
+        cfg.ts, cfg.windmodel = int(ts), int(windmodel)
+        cfg.dtype = capi.F64 if dtype == "f64" else capi.F32
+        cfg.device = int(device)
+        self._h = C.c_void_p()
+        check(L.tolfg_batch_create(C.byref(cfg), C.byref(self._h)))
+        n, neF, neG = C.c_int(), C.c_int(), C.c_int()
+        check(L.tolfg_batch_sizes(self._h, C.byref(n), C.byref(neF), C.byref(neG)))
+        self.n, self.neF, self.neG = n.value, neF.value, neG.value
+        self.mission, self.dtype, self.device = mission, dtype, int(device)
+        self.windmodel = windmodel
+        self.B = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().tolfg_batch_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def N(self):
+        return (self.n - 1) // 11 - 1
+
+    def pattern(self):
+        iG = np.zeros(self.neG, dtype=np.int32)
+        jG = np.zeros(self.neG, dtype=np.int32)
+        check(lib().tolfg_batch_pattern(self._h, _i(iG), _i(jG)))
+        return iG, jG
+
+    def set_trajectories(self, trajs):
+        arr = (Traj * len(trajs))()
+        for t, tr in enumerate(trajs):
+            arr[t].aircraft, arr[t].Vref, arr[t].href = tr.aircraft, tr.Vref, tr.href
+            arr[t].north_goal, arr[t].east_goal, arr[t].radius_goal = tr.north_goal, tr.east_goal, tr.radius_goal
+            arr[t].xi, arr[t].yi = tr.xi, tr.yi
+        check(lib().tolfg_batch_set_trajectories(self._h, len(trajs), arr))
+        self.B = len(trajs)
+
+    def x0(self, t, zi=0.0):
+        x = np.zeros(self.n)
+        check(lib().tolfg_batch_x0(self._h, int(t), float(zi), _d(x)))
+        return x
+
+    def bounds(self, t, zi=0.0):
+        xl, xu = np.zeros(self.n), np.zeros(self.n)
+        Fl, Fu = np.zeros(self.neF), np.zeros(self.neF)
+        check(lib().tolfg_batch_bounds(self._h, int(t), float(zi), _d(xl), _d(xu), _d(Fl), _d(Fu)))
+        return xl, xu, Fl, Fu
+
+    # ---- device buffers (torch is plumbing: memory + streams)
+    def torch_dtype(self):
+        import torch
+        return torch.float64 if self.dtype == "f64" else torch.float32
+
+    def alloc(self, B=None, pad=None):
+        """X, F, G device tensors with row strides padded to `pad` elements (default: 16 bytes)."""
+        import torch
+        B = self.B if B is None else B
+        v = pad if pad is not None else (2 if self.dtype == "f64" else 4)
+        up = lambda m: (m + v - 1) // v * v   # noqa: E731
+        dev = torch.device("cuda", self.device)
+        dt = self.torch_dtype()
+        X = torch.zeros((B, up(self.n)), dtype=dt, device=dev)
+        F = torch.zeros((B, up(self.neF)), dtype=dt, device=dev)
+        G = torch.zeros((B, up(self.neG)), dtype=dt, device=dev)
+        return X, F, G
+
+    def eval(self, X, F, G, wind=None, needF=True, needG=True, stream=None, B=None):
+        """Enqueue one evaluation on `stream` (default: torch's current stream)."""
+        import torch
+        B = X.shape[0] if B is None else B
+        if stream is None:
+            stream = torch.cuda.current_stream(X.device).cuda_stream
+        check(lib().tolfg_batch_eval(self._h, int(B), X.data_ptr(), X.stride(0), F.data_ptr(), F.stride(0),
+                                     G.data_ptr(), G.stride(0), None if wind is None else wind.data_ptr(),
+                                     int(needF), int(needG), C.c_void_p(stream)))
+
+    def objectives(self, F, out=None, stream=None, B=None):
+        import torch
+        B = F.shape[0] if B is None else B
+        if out is None:
+            out = torch.empty(B, dtype=F.dtype, device=F.device)
+        if stream is None:
+            stream = torch.cuda.current_stream(F.device).cuda_stream
+        check(lib().tolfg_batch_objectives(self._h, int(B), F.data_ptr(), F.stride(0), out.data_ptr(),
+                                           C.c_void_p(stream)))
+        return out
+
+    def algorithmic_bytes(self, B=None):
+        return lib().tolfg_batch_algorithmic_bytes(self._h, int(self.B if B is None else B))
