@@ -172,6 +172,14 @@ int  tolfg_batch_eval(tolfg_batch *b, int B,
  * RCCL all-gather across GPUs. */
 int  tolfg_batch_objectives(tolfg_batch *b, int B, const void *dF, long ldf, void *dObj, void *stream);
 
+/* Measurement aid for bench.py's roofline line.  While enabled, every tolfg_batch_eval records a
+ * pair of HIP events on the launch stream immediately around fg_kernel (the dominant kernel; the
+ * small finalize kernel that follows is outside the pair).  tolfg_batch_kernel_time waits for the
+ * recorded launches, returns how many there were and their average / minimum duration in ms, and
+ * resets the record. */
+int  tolfg_batch_set_timing(tolfg_batch *b, int enable);
+int  tolfg_batch_kernel_time(tolfg_batch *b, double *avg_ms, double *min_ms);
+
 /* algorithmic bytes one evaluation of B trajectories moves: elemsize * B * (n + neF + neG)
  *  */
 double tolfg_batch_algorithmic_bytes(const tolfg_batch *b, int B);

@@ -317,6 +317,20 @@ int tolfg_batch_objectives(tolfg_batch *h, int B, const void *dF, long ldf, void
     return guarded([&] { h->b->objectives(B, dF, ldf, dObj, static_cast<hipStream_t>(stream)); });
 }
 
+int tolfg_batch_set_timing(tolfg_batch *h, int enable)
+{
+    if (!h) return fail(TOLFG_ERR_ARG, "null batch");
+    return guarded([&] { h->b->set_timing(enable != 0); });
+}
+
+int tolfg_batch_kernel_time(tolfg_batch *h, double *avg_ms, double *min_ms)
+{
+    if (!h) return fail(TOLFG_ERR_ARG, "null batch");
+    int n = 0;
+    const int rc = guarded([&] { n = h->b->kernel_time(avg_ms, min_ms); });
+    return rc == TOLFG_OK ? n : rc;
+}
+
 double tolfg_batch_algorithmic_bytes(const tolfg_batch *h, int B)
 {
     if (!h) return 0.0;

@@ -35,15 +35,29 @@ struct FgArgs {
     void          *G;      long ldg;
     const void    *wind;   // [B][12][N+1] (ENU, reference member order) or nullptr
     const TrajDev *traj;   // [B]
-    int  B, N, tiles, c0;
+    int  B, N, c0;
+    int  tiles, nt;        // tiles per trajectory and nodes per tile, from plan_tiles()
+    int  ipb;              // consecutive tiles one workgroup walks (window prefetch depth 1)
     int  needF, needG;
+    double *partial;       // [B*tiles][2] objective partials (sum T^2, sum (r-R)^2), device
     double kT, kp, kv, kdt;
     AcCoef ac[MAX_AIRCRAFT];
+#ifdef TOLFG_STAMPS
+    // diagnostic build only (tools/fgprobe.cpp): per-wave s_memtime stamps, 8 per workgroup, and a
+    // variant selector for ablations.  The product library is never compiled with TOLFG_STAMPS.
+    unsigned long long *stamps;
+    int variant;
+#endif
 };
 
-// One fused launch: F and G of B trajectories.  dtype: 0 = f64, 1 = f32.  vec = elements per
+// Tiling of one trajectory's N dynamic nodes: `tiles` tiles of `nt` nodes (the last may be short).
+void plan_tiles(int N, int dtype, int *tiles, int *nt);
+
+// One evaluation = fg_kernel + finalize_kernel on stream s: F and G of B trajectories.  dtype: 0 = f64, 1 = f32.  vec = elements per
 // 16-byte access the caller has verified alignment for (f64: 2 or 1; f32: 4 or 1).
-hipError_t launch_fg(const FgArgs &a, int mission, int wind, int dtype, int vec, hipStream_t s);
+// t0/t1 (may be null) are recorded on s immediately around fg_kernel, the dominant kernel.
+hipError_t launch_fg(const FgArgs &a, int mission, int wind, int dtype, int vec, hipStream_t s,
+                     hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
 
 // dObj[t] = F[t*ldf]
 hipError_t launch_objectives(const void *F, long ldf, void *obj, int B, int dtype, hipStream_t s);

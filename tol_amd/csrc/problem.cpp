@@ -5,6 +5,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include <hip/hip_runtime_api.h>
@@ -77,7 +78,7 @@ batch::batch(const std::string &mission, const std::string &root, const std::vec
     sz_ = make_sizes(mid, N);
 
     args_.N = N;
-    args_.tiles = (N + 63) / 64;
+    plan_tiles(N, dtype, &args_.tiles, &args_.nt);
     args_.c0 = sz_.c0;
     args_.kT = gn_.kT; args_.kp = gn_.kp; args_.kv = gn_.kv; args_.kdt = gn_.kdt;
     for (size_t i = 0; i < acs_.size(); ++i) {
@@ -92,6 +93,8 @@ batch::batch(const std::string &mission, const std::string &root, const std::vec
 batch::~batch()
 {
     if (d_traj_) (void)hipFree(d_traj_);
+    if (d_partial_) (void)hipFree(d_partial_);
+    for (hipEvent_t e : ev_) if (e) (void)hipEventDestroy(e);
 }
 
 double batch::chi_d(int t) const
@@ -143,16 +146,76 @@ void batch::eval(int B, const void *dX, long ldx, void *dF, long ldf, void *dG, 
         throw std::invalid_argument("eval: leading dimension smaller than the row");
     if (windmodel_ == TOLFG_WIND_TABLE && !dWind) throw std::invalid_argument("eval: table wind needs dWind");
     if (!uploaded_) upload();
+    const long W = (long)B * args_.tiles;
+    if (W > partial_cap_) {        // objective partials, 2 doubles per tile
+        check(hipSetDevice(device_), "hipSetDevice");
+        if (d_partial_) check(hipFree(d_partial_), "hipFree");
+        d_partial_ = nullptr;
+        check(hipMalloc(reinterpret_cast<void **>(&d_partial_), sizeof(double) * 2 * (size_t)W), "hipMalloc(partial)");
+        partial_cap_ = W;
+    }
     FgArgs a = args_;
+    a.partial = d_partial_;
+    a.ipb = items_per_block(W);
     a.X = dX; a.ldx = ldx; a.F = dF; a.ldf = ldf; a.G = dG; a.ldg = ldg;
     a.wind = dWind; a.traj = d_traj_;
     a.B = B; a.needF = needF ? 1 : 0; a.needG = needG ? 1 : 0;
     // 16-byte accesses need every row's x window and slab region on a 16-byte boundary
     const int vmax = dtype_ == TOLFG_F64 ? 2 : 4;
     const bool aligned = (reinterpret_cast<uintptr_t>(dX) % 16 == 0) && (ldx % vmax == 0) &&
+                         (!needF || ((reinterpret_cast<uintptr_t>(dF) % 16 == 0) && (ldf % vmax == 0))) &&
                          (!needG || ((reinterpret_cast<uintptr_t>(dG) % 16 == 0) && (ldg % vmax == 0) &&
                                      (sz_.c0 % vmax == 0)));
-    check(launch_fg(a, sz_.mission, kernel_wind(windmodel_), dtype_, aligned ? vmax : 1, stream), "launch fg");
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    if (timing_) {                 // HIP events on the launch stream, around fg_kernel only
+        if (ev_used_ + 2 > ev_.size()) {
+            const size_t old = ev_.size();
+            ev_.resize(old + 64, nullptr);
+            for (size_t i = old; i < ev_.size(); ++i) check(hipEventCreate(&ev_[i]), "hipEventCreate");
+        }
+        t0 = ev_[ev_used_++];
+        t1 = ev_[ev_used_++];
+    }
+    check(launch_fg(a, sz_.mission, kernel_wind(windmodel_), dtype_, aligned ? vmax : 1, stream, t0, t1), "launch fg");
+}
+
+void batch::set_timing(bool on)
+{
+    timing_ = on;
+    ev_used_ = 0;
+}
+
+int batch::kernel_time(double *avg_ms, double *min_ms)
+{
+    const int pairs = (int)(ev_used_ / 2);
+    double sum = 0, mn = 1e300;
+    for (int i = 0; i < pairs; ++i) {
+        check(hipEventSynchronize(ev_[2 * i + 1]), "hipEventSynchronize");
+        float ms = 0;
+        check(hipEventElapsedTime(&ms, ev_[2 * i], ev_[2 * i + 1]), "hipEventElapsedTime");
+        sum += ms;
+        if (ms < mn) mn = ms;
+    }
+    if (avg_ms) *avg_ms = pairs ? sum / pairs : 0.0;
+    if (min_ms) *min_ms = pairs ? mn : 0.0;
+    ev_used_ = 0;
+    return pairs;
+}
+
+int batch::items_per_block(long W) const
+{
+    // A workgroup walks `ipb` consecutive tiles and fetches tile i+1's x window while tile i streams
+    // out.  More tiles per workgroup hide more load latency; fewer keep the tail short.  Tuned on
+    // MI355X with tools/fgprobe.cpp; TOLFG_IPB overrides for experiments.
+    if (const char *e = std::getenv("TOLFG_IPB")) {
+        const int v = std::atoi(e);
+        if (v >= 1) return v;
+    }
+    // Measured (B = 4096, ts = 200, fp64): ipb 1 / 2 / 4 / 8 -> 4.54 / 4.47 / 4.16 / 4.13 TB/s.  Workgroups
+    // that walk several tiles start in lockstep and stay in phase, so loads, arithmetic and stores
+    // of different waves stop overlapping; one tile per workgroup lets the dispatcher stagger them.
+    (void)W;
+    return 1;
 }
 
 void batch::objectives(int B, const void *dF, long ldf, void *dObj, hipStream_t stream)

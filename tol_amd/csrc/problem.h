@@ -53,6 +53,9 @@ public:
     void eval(int B, const void *dX, long ldx, void *dF, long ldf, void *dG, long ldg, const void *dWind,
               int needF, int needG, hipStream_t stream);
     void objectives(int B, const void *dF, long ldf, void *dObj, hipStream_t stream);
+    // measurement aid: HIP events recorded on the launch stream around fg_kernel of every eval
+    void set_timing(bool on);
+    int kernel_time(double *avg_ms, double *min_ms);   // launches averaged since the last call
 
 private:
     Sizes sz_;
@@ -62,6 +65,12 @@ private:
     snopt sn_;
     int windmodel_, dtype_, device_;
     void upload();
+    int items_per_block(long W) const;
+    bool timing_ = false;
+    std::vector<hipEvent_t> ev_;
+    size_t ev_used_ = 0;
+    double *d_partial_ = nullptr;
+    long partial_cap_ = 0;
     int ntraj_ = 0, cap_ = 0;
     bool uploaded_ = false;
     TrajDev *d_traj_ = nullptr;

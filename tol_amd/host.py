@@ -255,5 +255,16 @@ class Batch:
                                            C.c_void_p(stream)))
         return out
 
+    def set_timing(self, on=True):
+        check(lib().tolfg_batch_set_timing(self._h, int(bool(on))))
+
+    def kernel_time(self):
+        """(launches, avg_ms, min_ms) of fg_kernel since the last call (HIP events on the launch stream)."""
+        a, m = C.c_double(), C.c_double()
+        n = lib().tolfg_batch_kernel_time(self._h, C.byref(a), C.byref(m))
+        if n < 0:
+            check(n)
+        return n, a.value, m.value
+
     def algorithmic_bytes(self, B=None):
         return lib().tolfg_batch_algorithmic_bytes(self._h, int(self.B if B is None else B))

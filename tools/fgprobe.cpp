@@ -1,0 +1,107 @@
+// fgprobe.cpp -- diagnostic harness for the fg kernel (NOT part of the product).
+//
+// Builds tol_amd/csrc/kernels.hip with -DTOLFG_STAMPS into a standalone program that
+//   * times the fused F+G launch on a synthetic S10/ts=200 batch with HIP events, and
+//   * reports where a dynamics-tile wavefront spends its cycles (s_memtime stamps, medians).
+// Stamp builds are for phase SHARES only; their run time is not a benchmark figure
+// (cdna_hip_programming.md section 7, "In-kernel stamps").
+//
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DTOLFG_STAMPS -o gpurun_out/fgprobe tools/fgprobe.cpp
+#include "../tol_amd/csrc/kernels.hip"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <vector>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+int main(int argc, char **argv)
+{
+    const int B = argc > 1 ? atoi(argv[1]) : 4096;
+    const int N = argc > 2 ? atoi(argv[2]) : 200;
+    const int reps = argc > 3 ? atoi(argv[3]) : 30;
+    const int variant = argc > 4 ? atoi(argv[4]) : 0;
+    const int n = 11 * (N + 1) + 1, neF = 8 * N + 12, neG = 107 * N + 37;
+    const long ldx = (n + 1) & ~1L, ldf = (neF + 1) & ~1L, ldg = (neG + 1) & ~1L;
+
+    std::vector<double> X((size_t)B * ldx);
+    std::mt19937_64 rng(7);
+    std::uniform_real_distribution<double> U(-1, 1);
+    for (int b = 0; b < B; b++) {
+        double *x = &X[(size_t)b * ldx];
+        x[0] = 0.1;
+        for (int k = 0; k <= N; k++) {
+            double *s = x + 11 * k + 1;
+            s[0] = 100 * U(rng); s[1] = 100 * U(rng); s[2] = -50 + 20 * U(rng); s[3] = 15 + 3 * U(rng);
+            s[4] = 0.2 * U(rng); s[5] = 3.1 * U(rng); s[6] = 0.3 * U(rng); s[7] = 0.8 + 0.2 * U(rng);
+            s[8] = 0.1 * U(rng); s[9] = 0.1 * U(rng); s[10] = 10 + 5 * U(rng);
+        }
+    }
+    std::vector<tolfg::TrajDev> tr(B);
+    for (int b = 0; b < B; b++) tr[b] = tolfg::TrajDev{0.24, 0.0, 400.0, 100.0, 0.0, 1.0, 0, 0};
+
+    double *dX, *dF, *dG; tolfg::TrajDev *dT; unsigned long long *dS;
+    int tiles, nt;
+    tolfg::plan_tiles(N, 0, &tiles, &nt);
+    const int ipb = (variant & 255) > 0 ? (variant & 255) : 1;
+    const long W = (long)B * tiles;
+    const long blocks = (W + ipb - 1) / ipb;
+    double *dP;
+    CK(hipMalloc(&dP, sizeof(double) * 2 * W));
+    CK(hipMalloc(&dX, sizeof(double) * X.size()));
+    CK(hipMalloc(&dF, sizeof(double) * B * ldf));
+    CK(hipMalloc(&dG, sizeof(double) * B * ldg));
+    CK(hipMalloc(&dT, sizeof(tolfg::TrajDev) * B));
+    CK(hipMalloc(&dS, sizeof(unsigned long long) * 10 * blocks));
+    CK(hipMemcpy(dX, X.data(), sizeof(double) * X.size(), hipMemcpyHostToDevice));
+    CK(hipMemcpy(dT, tr.data(), sizeof(tolfg::TrajDev) * B, hipMemcpyHostToDevice));
+    CK(hipMemset(dS, 0, sizeof(unsigned long long) * 10 * blocks));
+
+    tolfg::FgArgs a{};
+    a.X = dX; a.ldx = ldx; a.F = dF; a.ldf = ldf; a.G = dG; a.ldg = ldg; a.wind = nullptr; a.traj = dT;
+    a.B = B; a.N = N; a.tiles = tiles; a.nt = nt; a.ipb = ipb; a.partial = dP; a.c0 = 3 * N + 4; a.needF = 1; a.needG = 1;
+    a.kT = 0; a.kp = 8; a.kv = 0; a.kdt = 1;
+    a.ac[0] = tolfg::AcCoef{1.0 / 6.1228, 1.2682 * 0.6316 / (2 * 6.1228), 0.03, 1.0 / (16.4457 * M_PI * 0.9693)};
+    a.stamps = dS; a.variant = variant;
+
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    if (variant & 8192) a.needF = 0;
+    for (int i = 0; i < 5; i++) CK(tolfg::launch_fg(a, tolfg::MISSION_S10, tolfg::WIND_SHEAR, 0, 2, nullptr));
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < reps; i++) CK(tolfg::launch_fg(a, tolfg::MISSION_S10, tolfg::WIND_SHEAR, 0, 2, nullptr));
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    const double bytes = 8.0 * B * ((double)n + neF + neG);
+    printf("B=%d N=%d variant=%d: %.2f us/launch  %.1f GB/s algorithmic (stamped build, not a benchmark)\n", B, N,
+           variant, 1e3 * ms / reps, bytes / (1e6 * ms / reps));
+
+    std::vector<unsigned long long> S((size_t)10 * blocks);
+    CK(hipMemcpy(S.data(), dS, sizeof(unsigned long long) * S.size(), hipMemcpyDeviceToHost));
+    // stamps of the LAST tile a workgroup walked
+    const char *names[6] = {"wait window + regs->LDS + barrier", "LDS->regs, issue next window", "node_eval, F + cost stores, rows->LDS",
+                            "G slab stores (issue)", "loop exit", "drain vmcnt(0)"};
+    std::vector<std::vector<double>> d(7);
+    std::vector<double> clk;
+    for (long id = 0; id < blocks; id++) {
+        const unsigned long long *s = &S[(size_t)id * 10];
+        if (!s[0] || !s[6]) continue;
+        for (int i = 0; i < 6; i++) d[i].push_back((double)(s[i + 1] - s[i]));
+        d[6].push_back((double)(s[6] - s[0]));
+        if (s[8] > s[7]) clk.push_back((double)(s[6] - s[0]) / (double)(s[8] - s[7]) * 100.0);
+    }
+    auto med = [](std::vector<double> &v) { std::sort(v.begin(), v.end()); return v.empty() ? 0.0 : v[v.size() / 2]; };
+    const double tot = med(d[6]);
+    printf("in-kernel clock (d s_memtime / d s_memrealtime x 100 MHz), median over workgroups: %.0f MHz\n", med(clk));
+    printf("tiles=%d nt=%d ipb=%d: %zu workgroups, median span of the last tile %.0f cycles (s_memtime ticks)\n", tiles, nt, ipb, d[6].size(), tot);
+    for (int i = 0; i < 6; i++) {
+        const double m = med(d[i]);
+        printf("  %-34s %9.0f cycles  %5.1f %%\n", names[i], m, 100.0 * m / tot);
+    }
+    return 0;
+}

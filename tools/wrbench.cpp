@@ -1,0 +1,75 @@
+// wrbench.cpp -- write-pattern microbenchmark (diagnostic, NOT part of the product).
+//
+// Question it answers: which shapes of concurrent 16-B/lane store streams does the MI355X memory
+// system sustain beyond the 256 MiB Infinity Cache?  The fg kernel writes ~53 KB sequentially per
+// wavefront from ~1800 concurrently resident waves; a plain fill writes 1 KiB per wave in launch
+// order.  Patterns:
+//   mode 0: every wave writes S KiB sequentially (S store instructions of 1 KiB) to segment = block id
+//   mode 1: groups of GRP consecutive waves share a GRP*S KiB region and interleave KiB chunks
+//   mode 2: like 0 but each store instruction is followed by `delay` x s_sleep (slow producer)
+// LDS bytes per block (dynamic) limit the occupancy like the real kernel's 22 KB does.
+//
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o tools/bin/wrbench tools/wrbench.cpp
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+typedef double vec2 __attribute__((ext_vector_type(2)));
+
+template <int MODE>
+__global__ __launch_bounds__(64) void wr(vec2 *out, int S, int grp, int delay, long nblocks)
+{
+    extern __shared__ char smem[];
+    const int lane = threadIdx.x;
+    if (smem == nullptr) return;
+    const long id = blockIdx.x;
+    vec2 v = {1.0 + lane, 2.0};
+    if (MODE == 1) {
+        const long g = id / grp, w = id % grp;
+        vec2 *base = out + (g * grp * S) * 64;
+        for (int i = 0; i < S; i++) base[((long)i * grp + w) * 64 + lane] = v;
+    } else {
+        vec2 *base = out + id * S * 64;
+        for (int i = 0; i < S; i++) {
+            base[(long)i * 64 + lane] = v;
+            if (MODE == 2)
+                for (int d = 0; d < delay; d++) __builtin_amdgcn_s_sleep(8);
+        }
+    }
+}
+
+int main(int argc, char **argv)
+{
+    const int mode = argc > 1 ? atoi(argv[1]) : 0;
+    const int S = argc > 2 ? atoi(argv[2]) : 52;
+    const int lds = argc > 3 ? atoi(argv[3]) : 0;
+    const int grp = argc > 4 ? atoi(argv[4]) : 8;
+    const int delay = argc > 5 ? atoi(argv[5]) : 0;
+    const long total = 800L << 20;
+    const long nblocks = total / (1024L * S);
+    vec2 *d;
+    CK(hipMalloc(&d, total + (1 << 20)));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    auto launch = [&]() {
+        if (mode == 0) hipLaunchKernelGGL(wr<0>, dim3(nblocks), dim3(64), lds, 0, d, S, grp, delay, nblocks);
+        if (mode == 1) hipLaunchKernelGGL(wr<1>, dim3(nblocks / grp * grp), dim3(64), lds, 0, d, S, grp, delay, nblocks);
+        if (mode == 2) hipLaunchKernelGGL(wr<2>, dim3(nblocks), dim3(64), lds, 0, d, S, grp, delay, nblocks);
+    };
+    for (int i = 0; i < 3; i++) launch();
+    CK(hipDeviceSynchronize());
+    const int reps = 20;
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < reps; i++) launch();
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    const double bytes = (double)nblocks * S * 1024.0;
+    printf("mode %d S %3d KiB/wave lds %6d grp %3d delay %3d: %8.1f us  %7.1f GB/s\n", mode, S, lds, grp, delay,
+           1e3 * ms / reps, bytes / (1e6 * ms / reps));
+    return 0;
+}
