@@ -1,0 +1,114 @@
+"""The C-ABI library: it loads, exports every symbol include/tolfg.h declares, and its host-side
+set-up (sizes, pattern, initial guess, bounds) equals the oracle's.  No GPU is needed for any of this;
+evaluation without a GPU must fail loudly (there is no CPU path in the product)."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+AIRCRAFT = ["tempest", "skywalker", "tempest_eric", "tempest_wences", "tempest_will"]
+
+
+def declared_functions():
+    text = open(os.path.join(ROOT, "include", "tolfg.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = set(re.findall(r"\b(tolfg_[a-zA-Z0-9_]+|DEFINEGusrfg_)\s*\(", text))
+    return names - {"tolfg_config", "tolfg_traj", "tolfg_batch_config"}
+
+
+def test_every_declared_symbol_is_exported_and_bound(tolfg):
+    from tol_amd import capi
+    declared = declared_functions()
+    assert "DEFINEGusrfg_" in declared and len(declared) >= 25
+    out = subprocess.run(["nm", "-D", "--defined-only", tolfg.lib_path()], capture_output=True, text=True, check=True).stdout
+    exported = {line.split()[-1] for line in out.splitlines() if " T " in line}
+    assert declared <= exported, declared - exported
+    assert declared == set(capi.SYMBOLS), declared ^ set(capi.SYMBOLS)
+    L = tolfg.lib()
+    for name in declared:
+        assert getattr(L, name) is not None
+    assert L.tolfg_version().startswith(b"tolfg")
+    assert os.path.isdir(os.path.join(L.tolfg_default_root().decode(), "aircraft"))
+
+
+def test_library_does_not_pin_a_hip_runtime(tolfg):
+    """One HIP runtime per process: the library must not carry its own DT_NEEDED for libamdhip64
+    (it would pull a second copy next to torch's and neither could open the GPU)."""
+    from tol_amd import capi
+    out = subprocess.run(["readelf", "-d", tolfg.lib_path()], capture_output=True, text=True, check=True).stdout
+    assert "libamdhip64" not in out
+    assert len(capi.mapped_hip_runtimes()) == 1
+
+
+@pytest.mark.parametrize("mission", ["S10", "G7"])
+@pytest.mark.parametrize("aircraft", AIRCRAFT)
+@pytest.mark.parametrize("N", [0, 1, 7, 100, 200])
+def test_setup_matches_oracle(tolfg, oracle, mission, aircraft, N):
+    rg = 100.0 if mission == "S10" else 0.0
+    p = tolfg.Problem(mission, aircraft, ts=N, east_goal=350.0, north_goal=40.0, radius_goal=rg, start=(3.0, -4.0, -20.0))
+    o = oracle.Problem(mission, aircraft, N=(N or None), east_goal=350.0, north_goal=40.0, radius_goal=rg, start=(3.0, -4.0, -20.0))
+    assert (p.n, p.neF, p.neG) == (o.n, o.neF, o.neG)
+    for a, b in zip(p.pattern(), o.pattern()):
+        assert np.array_equal(a, b)
+    assert np.array_equal(p.x0(), o.x0())
+    for a, b in zip(p.bounds(), o.bounds()):
+        assert np.array_equal(a, b)
+    assert p.tolerances() == (o.opt_tol, o.feas_tol)
+    p.close()
+
+
+def test_batch_setup_matches_oracle(tolfg, oracle):
+    bt = tolfg.Batch("G7", AIRCRAFT, ts=33)
+    trajs = [tolfg.Trajectory(aircraft=t % 5, north_goal=10.0 * t, east_goal=300.0 + t, radius_goal=0.0, xi=1.0 * t, yi=-2.0 * t)
+             for t in range(7)]
+    bt.set_trajectories(trajs)
+    for t, tr in enumerate(trajs):
+        o = oracle.Problem("G7", AIRCRAFT[tr.aircraft], N=33, east_goal=tr.east_goal, north_goal=tr.north_goal,
+                           radius_goal=0.0, start=(tr.xi, tr.yi, -30.0))
+        assert np.array_equal(bt.x0(t, zi=-30.0), o.x0())
+        for a, b in zip(bt.bounds(t, zi=-30.0), o.bounds()):
+            assert np.array_equal(a, b)
+    for a, b in zip(bt.pattern(), o.pattern()):
+        assert np.array_equal(a, b)
+    assert bt.algorithmic_bytes(7) == 8 * 7 * (bt.n + bt.neF + bt.neG)
+
+
+def test_bad_arguments(tolfg):
+    with pytest.raises(tolfg.TolfgError):
+        tolfg.Problem("Q1", "tempest")
+    with pytest.raises(tolfg.TolfgError):
+        tolfg.Batch("S10", [])
+    with pytest.raises(tolfg.TolfgError):
+        tolfg.Batch("S10", ["tempest"] * 9)
+    bt = tolfg.Batch("S10", ["tempest"])
+    with pytest.raises(tolfg.TolfgError):
+        bt.set_trajectories([tolfg.Trajectory(aircraft=3)])
+
+
+def test_no_current_problem_sets_status(tolfg):
+    import ctypes as C
+    L = tolfg.lib()
+    L.tolfg_set_current(None)
+    st, n, z = C.c_int(1), C.c_int(3), C.c_int(0)
+    one = C.c_int(1)
+    x = (C.c_double * 3)()
+    L.DEFINEGusrfg_(C.byref(st), C.byref(n), x, C.byref(one), C.byref(n), x, C.byref(z), C.byref(n), x,
+                    None, C.byref(z), None, C.byref(z), None, C.byref(z))
+    assert st.value == -2
+
+
+def test_evaluation_without_a_gpu_fails_loudly(tolfg):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    p = tolfg.Problem("S10", "tempest")
+    F, G, st = p.define_fg(p.x0())
+    assert st == -2                     # snOptA: terminate; nothing was computed on the CPU
+    assert (F == 0).all() and (G == 0).all()
+    with pytest.raises(tolfg.TolfgError) as e:
+        p.computeF(p.x0())
+    assert e.value.code == -3
