@@ -120,6 +120,9 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-callback", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend for N > 1; gloo (objectives staged through host memory) only "
+                         "rehearses the multi-rank step loop when several ranks must share one GPU")
     args = ap.parse_args()
 
     import torch
@@ -134,10 +137,16 @@ def main():
             sys.exit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    ndev = torch.cuda.device_count()
+    if args.backend == "gloo":
+        local = local % max(ndev, 1)               # rehearsal: ranks may share a GPU
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group("gloo")
 
     B = args.batch
     bt = tol_amd.Batch(args.mission, (args.aircraft,), ts=args.ts, dtype=args.dtype, device=local)
@@ -146,17 +155,18 @@ def main():
     dX[:, :bt.n] = torch.from_numpy(X).to(bt.torch_dtype()).cuda()
     del X
     obj = [torch.empty(B, dtype=dF.dtype, device=dF.device) for _ in range(2)]
-    allobj = [torch.empty(B * world, dtype=dF.dtype, device=dF.device) for _ in range(2)] if world > 1 else None
+    gdev = dF.device if args.backend == "nccl" else torch.device("cpu")
+    allobj = [torch.empty(B * world, dtype=dF.dtype, device=gdev) for _ in range(2)] if world > 1 else None
     pending = [None, None]
 
     def step(i):
-        bt.eval(dX, dF, dG)
         s = i & 1
         if world > 1 and pending[s] is not None:
             pending[s].wait()                      # buffer reuse: the gather of step i-2 must be done
-        bt.objectives(dF, out=obj[s])
+        bt.eval(dX, dF, dG, obj=obj[s])            # finalize_kernel also writes the objectives, contiguous
         if world > 1:
-            pending[s] = dist.all_gather_into_tensor(allobj[s], obj[s], async_op=True)
+            src = obj[s] if args.backend == "nccl" else obj[s].cpu()
+            pending[s] = dist.all_gather_into_tensor(allobj[s], src, async_op=True)
 
     def fence():
         for s in (0, 1):
@@ -190,6 +200,9 @@ def main():
     # sanity: the objectives that came back are finite and, on N > 1, every rank's shard arrived
     final = allobj[(args.steps - 1) & 1] if world > 1 else obj[(args.steps - 1) & 1]
     assert torch.isfinite(final).all(), "non-finite objective in the gathered result"
+    if world > 1:   # this rank's shard sits at its place in the gathered vector
+        mine = obj[(args.steps - 1) & 1].to(final.device)
+        assert torch.equal(final[rank * B:(rank + 1) * B], mine), "gathered objectives are out of order"
 
     if rank == 0:
         nodes_per_step = B * world * args.ts

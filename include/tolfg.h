@@ -163,13 +163,14 @@ int  tolfg_batch_bounds(const tolfg_batch *b, int t, double zi,
 /* Evaluate F and G of trajectories [0,B) in one launch.  dX, dF, dG, dWind are DEVICE pointers to
  * elements of the batch dtype; row t of X/F/G starts ldx/ldf/ldg elements after row t-1
  * (ld >= n / neF / neG; even ld keeps 16-byte stores).  dWind is NULL unless windmodel is
- * TOLFG_WIND_TABLE, then [B][12][ts+1].  stream is a hipStream_t (NULL = default stream).
- * Asynchronous: returns after enqueueing. */
+ * TOLFG_WIND_TABLE, then [B][12][ts+1].  dObj is NULL or a device array of B elements that also
+ * receives the objectives F[t][0], contiguous (needs needF).  stream is a hipStream_t (NULL =
+ * default stream).  Asynchronous: returns after enqueueing. */
 int  tolfg_batch_eval(tolfg_batch *b, int B,
                       const void *dX, long ldx, void *dF, long ldf, void *dG, long ldg,
-                      const void *dWind, int needF, int needG, void *stream);
+                      const void *dWind, int needF, int needG, void *dObj, void *stream);
 /* dObj[t] = F[t][0] for t in [0,B): the per-trajectory objectives, contiguous, ready for the
- * RCCL all-gather across GPUs. */
+ * RCCL all-gather across GPUs (a separate small kernel; tolfg_batch_eval's dObj does it for free). */
 int  tolfg_batch_objectives(tolfg_batch *b, int B, const void *dF, long ldf, void *dObj, void *stream);
 
 /* Measurement aid for bench.py's roofline line.  While enabled, every tolfg_batch_eval records a

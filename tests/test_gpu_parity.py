@@ -127,9 +127,11 @@ def test_batch_matches_oracle(tolfg, oracle, mission, dtype, pad):
     tdt = bt.torch_dtype()
     dX[:, :bt.n] = torch.from_numpy(X).to(tdt).cuda()
     dF.fill_(float("nan")); dG.fill_(float("nan"))
-    bt.eval(dX, dF, dG)
+    obj2 = torch.full((B,), float("nan"), dtype=tdt, device=dX.device)
+    bt.eval(dX, dF, dG, obj=obj2)
     obj = bt.objectives(dF)
     torch.cuda.synchronize()
+    assert torch.equal(obj, obj2)                 # fused objective output == separate gather kernel
     F = dF[:, :bt.neF].double().cpu().numpy()
     G = dG[:, :bt.neG].double().cpu().numpy()
     # padding columns must not be written

@@ -76,7 +76,7 @@ SYMBOLS = {
     "tolfg_batch_x0": (C.c_int, [C.c_void_p, C.c_int, C.c_double, _dp]),
     "tolfg_batch_bounds": (C.c_int, [C.c_void_p, C.c_int, C.c_double, _dp, _dp, _dp, _dp]),
     "tolfg_batch_eval": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_long, C.c_void_p, C.c_long,
-                                   C.c_void_p, C.c_long, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+                                   C.c_void_p, C.c_long, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "tolfg_batch_objectives": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_long, C.c_void_p, C.c_void_p]),
     "tolfg_batch_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "tolfg_batch_kernel_time": (C.c_int, [C.c_void_p, _dp, _dp]),

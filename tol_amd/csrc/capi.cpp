@@ -303,11 +303,12 @@ int tolfg_batch_bounds(const tolfg_batch *h, int t, double zi, double *xlow, dou
 }
 
 int tolfg_batch_eval(tolfg_batch *h, int B, const void *dX, long ldx, void *dF, long ldf, void *dG, long ldg,
-                     const void *dWind, int needF, int needG, void *stream)
+                     const void *dWind, int needF, int needG, void *dObj, void *stream)
 {
     if (!h) return fail(TOLFG_ERR_ARG, "null batch");
+    if (dObj && !needF) return fail(TOLFG_ERR_ARG, "dObj needs needF");
     return guarded([&] {
-        h->b->eval(B, dX, ldx, dF, ldf, dG, ldg, dWind, needF, needG, static_cast<hipStream_t>(stream));
+        h->b->eval(B, dX, ldx, dF, ldf, dG, ldg, dWind, needF, needG, static_cast<hipStream_t>(stream), dObj);
     });
 }
 

@@ -37,9 +37,9 @@ struct FgArgs {
     const TrajDev *traj;   // [B]
     int  B, N, c0;
     int  tiles, nt;        // tiles per trajectory and nodes per tile, from plan_tiles()
-    int  ipb;              // consecutive tiles one workgroup walks (window prefetch depth 1)
     int  needF, needG;
     double *partial;       // [B*tiles][2] objective partials (sum T^2, sum (r-R)^2), device
+    void   *obj;           // optional [B]: finalize_kernel also writes the objectives here, contiguous
     double kT, kp, kv, kdt;
     AcCoef ac[MAX_AIRCRAFT];
 #ifdef TOLFG_STAMPS

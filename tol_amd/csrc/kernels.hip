@@ -2,14 +2,14 @@
 //
 // One launch evaluates F and G of a batch of trajectories.  Work decomposition:
 //
-//   * fg_kernel: one 64-lane wavefront = one workgroup walks `ipb` consecutive TILES; a tile is up
-//     to 64 consecutive collocation nodes of one trajectory, lane = node.  Per node it produces the
+//   * fg_kernel: one 64-lane wavefront = one workgroup = one TILE; a tile is up to 64 consecutive
+//     collocation nodes of one trajectory, lane = node.  Per node it produces the
 //     defects F[8k+1..8k+8], the contiguous 104-element Jacobian slab, the node's objective-gradient
 //     entries and its objective terms (ref: problem::dynamicConstraints src/problem.cpp:929-1021,
 //     problem::dynamicsGradients src/problem.cpp:1035-1208, wind models 0/1 src/problem.cpp:480-531,
 //     problemS10::cost/costGradient src/problemS10.cpp:227-386, problemG7::... src/problemG7.cpp:225-384).
-//     The x window of the NEXT tile is fetched into registers before the current tile's stores are
-//     issued, so load latency hides under the store stream (measured: it was 45 % of a wave's life).
+//     One tile per workgroup on purpose: workgroups that walk several tiles (with the next window
+//     prefetched) start in lockstep and stay in phase, and measured 5-10 % slower.
 //   * finalize_kernel: one thread per trajectory adds the tiles' objective partials in tile order
 //     (deterministic, no atomics), handles the last node's objective terms and writes the boundary
 //     rows and their gradients (ref: src/problemS10.cpp:273-305,395-415; src/problemG7.cpp:258-296,
@@ -307,27 +307,6 @@ __device__ __forceinline__ void store_defects(T *p, const T (&d)[8])
     }
 }
 
-// Which tile a work item is, and where its x window lives.
-template <typename T> struct Item {
-    int b, k0, cnt, nvec;        // trajectory, first node, nodes, window vectors
-    const T *xwin;               // = xrow + 11*k0 (16-byte aligned when VEC > 1)
-};
-
-template <typename T, int VEC>
-__device__ __forceinline__ Item<T> make_item(const FgArgs &a, int item)
-{
-    Item<T> it;
-    it.b = item / a.tiles;
-    const int t = item - it.b * a.tiles;
-    it.k0 = t * a.nt;
-    it.cnt = min(a.nt, a.N - it.k0);
-    // window = x[11*k0 .. 11*(k0+cnt)+9): one element before node k0 (keeps the start aligned)
-    // up to the 8 states of node k0+cnt; rounded up to whole vectors, which stays inside the row
-    it.nvec = (NI * it.cnt + 9 + VEC - 1) / VEC;
-    it.xwin = static_cast<const T *>(a.X) + (long)it.b * a.ldx + NI * it.k0;
-    return it;
-}
-
 template <typename T, int MISSION, int WIND, int VEC>
 __global__ __launch_bounds__(TILE, TOLFG_MIN_WAVES_PER_SIMD) void fg_kernel(const FgArgs a)
 {
@@ -335,133 +314,122 @@ __global__ __launch_bounds__(TILE, TOLFG_MIN_WAVES_PER_SIMD) void fg_kernel(cons
     constexpr int NW = ((NI * TILE + 9 + VEC - 1) / VEC + TILE - 1) / TILE;   // window vectors per lane
     __shared__ __attribute__((aligned(16))) T lds[TILE * RS];
     const int lane = threadIdx.x;
-    const int W = a.B * a.tiles;
-    int item = blockIdx.x * a.ipb;
-    const int end = min(W, item + a.ipb);
-    if (item >= end) return;
+    const int N = a.N;
+    // workgroup -> (trajectory, tile); consecutive workgroups walk the batch's memory in order
+    const int item = blockIdx.x;
+    const int b = item / a.tiles;
+    const int k0 = (item - b * a.tiles) * a.nt;
+    const int cnt = min(a.nt, N - k0);
+    const T *xrow = static_cast<const T *>(a.X) + (long)b * a.ldx;
+    T *Frow = static_cast<T *>(a.F) + (long)b * a.ldf;
+    T *Grow = static_cast<T *>(a.G) + (long)b * a.ldg;
 
-    SlabOffsets<T, VEC> so;
-    if (a.needG) so.init(lane);
-
-    // fetch the first tile's window; later windows are fetched one tile ahead
-    vec win[NW];
-    Item<T> cur = make_item<T, VEC>(a, item);
+    // ---- x window = x[11*k0 .. 11*(k0+cnt)+9): one element before node k0 (keeps the start 16-byte
+    // aligned) up to the 8 states of node k0+cnt, rounded up to whole vectors (stays inside the row);
+    // contiguous 16-byte loads -> LDS -> this lane's node (transpose)
     TOLFG_REALTIME(a, 7);
     TOLFG_STAMP(a, 0);
-#pragma unroll
-    for (int j = 0; j < NW; j++) {
-        const int i = lane + TILE * j;
-        if (i < cur.nvec) win[j] = *reinterpret_cast<const vec *>(cur.xwin + (long)i * VEC);
-    }
-
-    for (; item < end; ++item) {
-        const int b = cur.b, k0 = cur.k0, cnt = cur.cnt, N = a.N;
-        const T *xrow = static_cast<const T *>(a.X) + (long)b * a.ldx;
-        T *Frow = static_cast<T *>(a.F) + (long)b * a.ldf;
-        T *Grow = static_cast<T *>(a.G) + (long)b * a.ldg;
-        const TrajDev tr = a.traj[b];
-        const T dt = xrow[0];
-
-        // ---- window: registers -> LDS -> this lane's node (transpose)
+    {
+        const int nvec = (NI * cnt + 9 + VEC - 1) / VEC;
+        const T *xwin = xrow + NI * k0;
+        vec win[NW];
 #pragma unroll
         for (int j = 0; j < NW; j++) {
             const int i = lane + TILE * j;
-            if (i < cur.nvec) *reinterpret_cast<vec *>(lds + i * VEC) = win[j];
+            if (i < nvec) win[j] = *reinterpret_cast<const vec *>(xwin + (long)i * VEC);
         }
-        __syncthreads();
-        TOLFG_STAMP(a, 1);
-        const bool act = lane < cnt;
-        const int ll = act ? lane : 0;         // idle lanes redo node k0; nothing of theirs is stored
-        T s[NI], sn[8], we[12];
 #pragma unroll
-        for (int m = 0; m < NI; m++) s[m] = lds[1 + NI * ll + m];
-#pragma unroll
-        for (int r = 0; r < 8; r++) sn[r] = lds[1 + NI * (ll + 1) + r];
-        if constexpr (WIND == WIND_TABLE) {
-            const T *wrow = static_cast<const T *>(a.wind) + (long)b * 12 * (N + 1);
-#pragma unroll
-            for (int f = 0; f < 12; f++) we[f] = wrow[(long)f * (N + 1) + k0 + ll];
-        } else {
-#pragma unroll
-            for (int f = 0; f < 12; f++) we[f] = T(0);
+        for (int j = 0; j < NW; j++) {
+            const int i = lane + TILE * j;
+            if (i < nvec) *reinterpret_cast<vec *>(lds + i * VEC) = win[j];
         }
-        __syncthreads();                       // the rows below overwrite the window
+    }
+    const TrajDev tr = a.traj[b];
+    const T dt = xrow[0];
+    __syncthreads();
+    TOLFG_STAMP(a, 1);
+    const bool act = lane < cnt;
+    const int ll = act ? lane : 0;             // idle lanes redo node k0; nothing of theirs is stored
+    T s[NI], sn[8], we[12];
+#pragma unroll
+    for (int m = 0; m < NI; m++) s[m] = lds[1 + NI * ll + m];
+#pragma unroll
+    for (int r = 0; r < 8; r++) sn[r] = lds[1 + NI * (ll + 1) + r];
+    if constexpr (WIND == WIND_TABLE) {
+        const T *wrow = static_cast<const T *>(a.wind) + (long)b * 12 * (N + 1);
+#pragma unroll
+        for (int f = 0; f < 12; f++) we[f] = wrow[(long)f * (N + 1) + k0 + ll];
+    } else {
+#pragma unroll
+        for (int f = 0; f < 12; f++) we[f] = T(0);
+    }
+    __syncthreads();                           // the rows below overwrite the window
+    TOLFG_STAMP(a, 2);
 
-        // ---- next tile's window: in flight while this tile is computed and streamed out
-        if (item + 1 < end) {
-            cur = make_item<T, VEC>(a, item + 1);
-#pragma unroll
-            for (int j = 0; j < NW; j++) {
-                const int i = lane + TILE * j;
-                if (i < cur.nvec) win[j] = *reinterpret_cast<const vec *>(cur.xwin + (long)i * VEC);
-            }
-        }
-        TOLFG_STAMP(a, 2);
-
-        const AcCoef &ac = a.ac[tr.ac];
-        T f[8];
-        NodeCtx<T, WIND> nc;
+    const AcCoef &ac = a.ac[tr.ac];
+    T f[8];
+    NodeCtx<T, WIND> nc;
 #ifdef TOLFG_STAMPS
-        if (TOLFG_VARIANT(a) & 256) {          // ablation: no arithmetic, outputs are garbage
+    if (TOLFG_VARIANT(a) & 256) {              // ablation: no arithmetic, outputs are garbage
 #pragma unroll
-            for (int r = 0; r < 8; r++) f[r] = s[r];
+        for (int r = 0; r < 8; r++) f[r] = s[r];
+    } else
+#endif
+    nc.rates(s, dt, T(tr.shear), we, T(ac.inv_m), T(ac.qk), T(ac.Cd0), T(ac.kind), f);
+
+    // ---- defects leave first (src/problem.cpp:1012-1019); sn dies here
+    if (a.needF && act && !(TOLFG_VARIANT(a) & 512)) {
+        T d8[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) d8[r] = sn[r] - f[r] * dt - s[r];
+        store_defects<T, VEC>(Frow + 1 + 8 * (k0 + lane), d8);
+    }
+
+    // ---- objective terms of this tile's nodes (node N is finalize_kernel's)
+    const T kT = T(a.kT), kp = T(a.kp);
+    T sumT = act ? s[10] * s[10] : T(0), sumP = T(0);
+    if constexpr (MISSION == MISSION_S10) {
+        // src/problemS10.cpp:247-262 (value), :346-375 (gradient)
+        const T dx = s[0] - T(tr.xg), dy = s[1] - T(tr.yg);
+        const T r = sqrt_t(dx * dx + dy * dy);
+        const T d = r - T(tr.rg);
+        if (act) sumP = d * d;
+        if (a.needG && act && !(TOLFG_VARIANT(a) & 1024)) {
+            T *gc = Grow + 1 + 3 * (k0 + lane);
+            gc[0] = kp * d * dx / r;
+            gc[1] = kp * d * dy / r;
+            gc[2] = kT * s[10];
+        }
+    } else {
+        // src/problemG7.cpp:364-368: one thrust entry per node, after (dt, x0, y0)
+        if (a.needG && act) Grow[3 + k0 + lane] = kT * s[10];
+    }
+    if (a.needF) {
+        sumT = wave_sum(sumT);
+        sumP = wave_sum(sumP);
+        if (lane == 0) {
+            a.partial[2 * (long)item + 0] = (double)sumT;
+            a.partial[2 * (long)item + 1] = (double)sumP;
+        }
+    }
+
+    if (a.needG) {
+        T *row = lds + lane * RS;
+#ifdef TOLFG_STAMPS
+        if (TOLFG_VARIANT(a) & 256) {
+#pragma unroll
+            for (int i = 0; i < 32; i++) row[i] = s[i % NI];
         } else
 #endif
-        nc.rates(s, dt, T(tr.shear), we, T(ac.inv_m), T(ac.qk), T(ac.Cd0), T(ac.kind), f);
-
-        // ---- defects leave first (src/problem.cpp:1012-1019); sn dies here
-        if (a.needF && act && !(TOLFG_VARIANT(a) & 512)) {
-            T d8[8];
-#pragma unroll
-            for (int r = 0; r < 8; r++) d8[r] = sn[r] - f[r] * dt - s[r];
-            store_defects<T, VEC>(Frow + 1 + 8 * (k0 + lane), d8);
-        }
-
-        // ---- objective terms of this tile's nodes (node N is finalize_kernel's)
-        const T kT = T(a.kT), kp = T(a.kp);
-        T sumT = act ? s[10] * s[10] : T(0), sumP = T(0);
-        if constexpr (MISSION == MISSION_S10) {
-            // src/problemS10.cpp:247-262 (value), :346-375 (gradient)
-            const T dx = s[0] - T(tr.xg), dy = s[1] - T(tr.yg);
-            const T r = sqrt_t(dx * dx + dy * dy);
-            const T d = r - T(tr.rg);
-            if (act) sumP = d * d;
-            if (a.needG && act && !(TOLFG_VARIANT(a) & 1024)) {
-                T *gc = Grow + 1 + 3 * (k0 + lane);
-                gc[0] = kp * d * dx / r;
-                gc[1] = kp * d * dy / r;
-                gc[2] = kT * s[10];
-            }
-        } else {
-            // src/problemG7.cpp:364-368: one thrust entry per node, after (dt, x0, y0)
-            if (a.needG && act) Grow[3 + k0 + lane] = kT * s[10];
-        }
-        if (a.needF) {
-            sumT = wave_sum(sumT);
-            sumP = wave_sum(sumP);
-            if (lane == 0) {
-                a.partial[2 * (long)item + 0] = (double)sumT;
-                a.partial[2 * (long)item + 1] = (double)sumP;
-            }
-        }
-
-        if (a.needG) {
-            T *row = lds + lane * RS;
-#ifdef TOLFG_STAMPS
-            if (TOLFG_VARIANT(a) & 256) {
-#pragma unroll
-                for (int i = 0; i < 32; i++) row[i] = s[i % NI];
-            } else
-#endif
-            nc.jacobian(f, row);
-            row[SL_ZERO] = T(0); row[SL_ONE] = T(1); row[SL_MONE] = T(-1);
-            __syncthreads();
-            TOLFG_STAMP(a, 3);
-            __builtin_amdgcn_sched_barrier(0);
-            if (!(TOLFG_VARIANT(a) & 2048)) store_slabs<T, VEC>(lds, Grow + a.c0 + (long)SLAB * k0, cnt, lane, so);
-            TOLFG_STAMP(a, 4);
-            __syncthreads();                   // next iteration's window overwrites the rows
-        }
+        nc.jacobian(f, row);
+        row[SL_ZERO] = T(0); row[SL_ONE] = T(1); row[SL_MONE] = T(-1);
+        __syncthreads();
+        TOLFG_STAMP(a, 3);
+        __builtin_amdgcn_sched_barrier(0);
+        SlabOffsets<T, VEC> so;
+        so.init(lane);
+        if (!(TOLFG_VARIANT(a) & 2048)) store_slabs<T, VEC>(lds, Grow + a.c0 + (long)SLAB * k0, cnt, lane, so);
+        TOLFG_STAMP(a, 4);
     }
     TOLFG_STAMP(a, 5);
 #ifdef TOLFG_STAMPS
@@ -505,7 +473,11 @@ __global__ __launch_bounds__(TILE) void finalize_kernel(const FgArgs a)
         const T d = r - T(tr.rg);
         if (a.needF) {
             sumP += d * d;
-            if (lane == 0) F[0] = T(0.5) * kT * sumT + T(0.5) * kp * sumP + T(a.kdt) * dt;   // src/problemS10.cpp:264
+            if (lane == 0) {                                                                  // src/problemS10.cpp:264
+                const T obj = T(0.5) * kT * sumT + T(0.5) * kp * sumP + T(a.kdt) * dt;
+                F[0] = obj;
+                if (a.obj) static_cast<T *>(a.obj)[b] = obj;
+            }
             if (lane < 11) {                                                                  // :292-303
                 T v = x[NI * N + 1 + lane] - x[1 + lane];
                 if (lane == 5) v = v - T(kTwoPi);
@@ -528,7 +500,11 @@ __global__ __launch_bounds__(TILE) void finalize_kernel(const FgArgs a)
         const T dist = sqrt_t(dxf * dxf + dyf * dyf);
         const T cchi = T(tr.cchi), schi = T(tr.schi);
         if (a.needF) {
-            if (lane == 0) F[0] = kT * T(0.5) * sumT + T(a.kv) * T(N) * dt / dist;           // src/problemG7.cpp:249
+            if (lane == 0) {                                                                  // src/problemG7.cpp:249
+                const T obj = kT * T(0.5) * sumT + T(a.kv) * T(N) * dt / dist;
+                F[0] = obj;
+                if (a.obj) static_cast<T *>(a.obj)[b] = obj;
+            }
             if (lane < 12) {                                                                  // :274-294
                 T v;
                 if (lane == 0) v = dxf - dist * cchi;
@@ -634,10 +610,10 @@ hipError_t launch_fg(const FgArgs &a, int mission, int wind, int dtype, int vec,
     if (a.B <= 0) return hipSuccess;
     int tiles, nt;
     plan_tiles(a.N, dtype, &tiles, &nt);
-    if (a.N < 1 || a.tiles != tiles || a.nt != nt || a.ipb < 1 || !a.partial) return hipErrorInvalidValue;
+    if (a.N < 1 || a.tiles != tiles || a.nt != nt || !a.partial) return hipErrorInvalidValue;
     const long W = (long)a.B * a.tiles;
     if (W > 0x7fffffffL) return hipErrorInvalidValue;
-    const dim3 grid((unsigned)((W + a.ipb - 1) / a.ipb));
+    const dim3 grid((unsigned)W);
     if (dtype == 0) {
         return mission == MISSION_S10 ? launch_wind<double, MISSION_S10>(a, wind, vec, grid, s, t0, t1)
                                       : launch_wind<double, MISSION_G7>(a, wind, vec, grid, s, t0, t1);

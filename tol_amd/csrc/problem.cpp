@@ -138,7 +138,7 @@ void batch::upload()
 }
 
 void batch::eval(int B, const void *dX, long ldx, void *dF, long ldf, void *dG, long ldg, const void *dWind,
-                 int needF, int needG, hipStream_t stream)
+                 int needF, int needG, hipStream_t stream, void *dObj)
 {
     if (B < 1 || B > ntraj_) throw std::invalid_argument("eval: B exceeds the described trajectories");
     if (!dX || (needF && !dF) || (needG && !dG)) throw std::invalid_argument("eval: null device pointer");
@@ -156,7 +156,7 @@ void batch::eval(int B, const void *dX, long ldx, void *dF, long ldf, void *dG, 
     }
     FgArgs a = args_;
     a.partial = d_partial_;
-    a.ipb = items_per_block(W);
+    a.obj = dObj;
     a.X = dX; a.ldx = ldx; a.F = dF; a.ldf = ldf; a.G = dG; a.ldg = ldg;
     a.wind = dWind; a.traj = d_traj_;
     a.B = B; a.needF = needF ? 1 : 0; a.needG = needG ? 1 : 0;
@@ -200,22 +200,6 @@ int batch::kernel_time(double *avg_ms, double *min_ms)
     if (min_ms) *min_ms = pairs ? mn : 0.0;
     ev_used_ = 0;
     return pairs;
-}
-
-int batch::items_per_block(long W) const
-{
-    // A workgroup walks `ipb` consecutive tiles and fetches tile i+1's x window while tile i streams
-    // out.  More tiles per workgroup hide more load latency; fewer keep the tail short.  Tuned on
-    // MI355X with tools/fgprobe.cpp; TOLFG_IPB overrides for experiments.
-    if (const char *e = std::getenv("TOLFG_IPB")) {
-        const int v = std::atoi(e);
-        if (v >= 1) return v;
-    }
-    // Measured (B = 4096, ts = 200, fp64): ipb 1 / 2 / 4 / 8 -> 4.54 / 4.47 / 4.16 / 4.13 TB/s.  Workgroups
-    // that walk several tiles start in lockstep and stay in phase, so loads, arithmetic and stores
-    // of different waves stop overlapping; one tile per workgroup lets the dispatcher stagger them.
-    (void)W;
-    return 1;
 }
 
 void batch::objectives(int B, const void *dF, long ldf, void *dObj, hipStream_t stream)

@@ -50,8 +50,9 @@ public:
     double chi_d(int t) const;
 
     // asynchronous on `stream`
+    // dObj (optional, needs needF): the objectives F[t][0] are also written there, contiguous
     void eval(int B, const void *dX, long ldx, void *dF, long ldf, void *dG, long ldg, const void *dWind,
-              int needF, int needG, hipStream_t stream);
+              int needF, int needG, hipStream_t stream, void *dObj = nullptr);
     void objectives(int B, const void *dF, long ldf, void *dObj, hipStream_t stream);
     // measurement aid: HIP events recorded on the launch stream around fg_kernel of every eval
     void set_timing(bool on);
@@ -65,7 +66,6 @@ private:
     snopt sn_;
     int windmodel_, dtype_, device_;
     void upload();
-    int items_per_block(long W) const;
     bool timing_ = false;
     std::vector<hipEvent_t> ev_;
     size_t ev_used_ = 0;

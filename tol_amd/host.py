@@ -234,15 +234,17 @@ class Batch:
         G = torch.zeros((B, up(self.neG)), dtype=dt, device=dev)
         return X, F, G
 
-    def eval(self, X, F, G, wind=None, needF=True, needG=True, stream=None, B=None):
-        """Enqueue one evaluation on `stream` (default: torch's current stream)."""
+    def eval(self, X, F, G, wind=None, needF=True, needG=True, stream=None, B=None, obj=None):
+        """Enqueue one evaluation on `stream` (default: torch's current stream).  `obj` (optional,
+        B elements) also receives the objectives F[:, 0], contiguous."""
         import torch
         B = X.shape[0] if B is None else B
         if stream is None:
             stream = torch.cuda.current_stream(X.device).cuda_stream
         check(lib().tolfg_batch_eval(self._h, int(B), X.data_ptr(), X.stride(0), F.data_ptr(), F.stride(0),
                                      G.data_ptr(), G.stride(0), None if wind is None else wind.data_ptr(),
-                                     int(needF), int(needG), C.c_void_p(stream)))
+                                     int(needF), int(needG), None if obj is None else obj.data_ptr(),
+                                     C.c_void_p(stream)))
 
     def objectives(self, F, out=None, stream=None, B=None):
         import torch

@@ -48,7 +48,7 @@ int main(int argc, char **argv)
     tolfg::plan_tiles(N, 0, &tiles, &nt);
     const int ipb = (variant & 255) > 0 ? (variant & 255) : 1;
     const long W = (long)B * tiles;
-    const long blocks = (W + ipb - 1) / ipb;
+    const long blocks = W; (void)ipb;
     double *dP;
     CK(hipMalloc(&dP, sizeof(double) * 2 * W));
     CK(hipMalloc(&dX, sizeof(double) * X.size()));
@@ -62,7 +62,7 @@ int main(int argc, char **argv)
 
     tolfg::FgArgs a{};
     a.X = dX; a.ldx = ldx; a.F = dF; a.ldf = ldf; a.G = dG; a.ldg = ldg; a.wind = nullptr; a.traj = dT;
-    a.B = B; a.N = N; a.tiles = tiles; a.nt = nt; a.ipb = ipb; a.partial = dP; a.c0 = 3 * N + 4; a.needF = 1; a.needG = 1;
+    a.B = B; a.N = N; a.tiles = tiles; a.nt = nt; a.partial = dP; a.obj = nullptr; a.c0 = 3 * N + 4; a.needF = 1; a.needG = 1;
     a.kT = 0; a.kp = 8; a.kv = 0; a.kdt = 1;
     a.ac[0] = tolfg::AcCoef{1.0 / 6.1228, 1.2682 * 0.6316 / (2 * 6.1228), 0.03, 1.0 / (16.4457 * M_PI * 0.9693)};
     a.stamps = dS; a.variant = variant;

@@ -31,6 +31,17 @@ __global__ __launch_bounds__(64) void wr(vec2 *out, int S, int grp, int delay, l
         const long g = id / grp, w = id % grp;
         vec2 *base = out + (g * grp * S) * 64;
         for (int i = 0; i < S; i++) base[((long)i * grp + w) * 64 + lane] = v;
+    } else if (MODE == 3) {       // XCD-contiguous: workgroups id and id+8 share an XCD -> give each XCD one region
+        const long seg = (id % 8) * (nblocks / 8) + id / 8;
+        vec2 *base = out + seg * S * 64;
+        for (int i = 0; i < S; i++) __builtin_nontemporal_store(v, &base[(long)i * 64 + lane]);
+    } else if (MODE == 4) {       // mode 0 with non-temporal stores
+        vec2 *base = out + id * S * 64;
+        for (int i = 0; i < S; i++) __builtin_nontemporal_store(v, &base[(long)i * 64 + lane]);
+    } else if (MODE == 5) {       // mode 1 (interleaved groups) with non-temporal stores
+        const long g = id / grp, w = id % grp;
+        vec2 *base = out + (g * grp * S) * 64;
+        for (int i = 0; i < S; i++) __builtin_nontemporal_store(v, &base[((long)i * grp + w) * 64 + lane]);
     } else {
         vec2 *base = out + id * S * 64;
         for (int i = 0; i < S; i++) {
@@ -58,6 +69,9 @@ int main(int argc, char **argv)
         if (mode == 0) hipLaunchKernelGGL(wr<0>, dim3(nblocks), dim3(64), lds, 0, d, S, grp, delay, nblocks);
         if (mode == 1) hipLaunchKernelGGL(wr<1>, dim3(nblocks / grp * grp), dim3(64), lds, 0, d, S, grp, delay, nblocks);
         if (mode == 2) hipLaunchKernelGGL(wr<2>, dim3(nblocks), dim3(64), lds, 0, d, S, grp, delay, nblocks);
+        if (mode == 3) hipLaunchKernelGGL(wr<3>, dim3(nblocks / 8 * 8), dim3(64), lds, 0, d, S, grp, delay, nblocks / 8 * 8);
+        if (mode == 4) hipLaunchKernelGGL(wr<4>, dim3(nblocks), dim3(64), lds, 0, d, S, grp, delay, nblocks);
+        if (mode == 5) hipLaunchKernelGGL(wr<5>, dim3(nblocks / grp * grp), dim3(64), lds, 0, d, S, grp, delay, nblocks);
     };
     for (int i = 0; i < 3; i++) launch();
     CK(hipDeviceSynchronize());
