@@ -1,0 +1,165 @@
+"""BASELINE.json configs[1..4] at their full sizes on the GPU, through the C ABI: oracle comparison
+where the oracle finishes in seconds, size-independent exact properties everywhere."""
+import numpy as np
+import pytest
+
+from helpers import assert_close
+
+pytestmark = pytest.mark.gpu
+
+AIRCRAFT = ["tempest", "skywalker", "tempest_eric", "tempest_wences", "tempest_will"]
+
+# structure of one 104-entry slab, 8 rows x [dt | x y z Va gam chi phi CL dphi dCL T | next]
+_ONE = [13 * r + 12 for r in range(8)]
+_MINUS_ONE = [1, 15, 29, 85, 99]
+_COMPUTED = [0, 4, 5, 6, 13, 17, 18, 19, 26, 30, 31, 39, 43, 44, 45, 47, 50, 52, 56, 57, 58, 59, 60,
+             65, 69, 70, 71, 72, 73, 78, 87, 91, 101]
+_ZERO = sorted(set(range(104)) - set(_ONE) - set(_MINUS_ONE) - set(_COMPUTED))
+
+
+def check_exact_structure(G, c0, N, x):
+    """58 structural zeros, 8 ones, 5 minus-ones per slab, and -dt in the two control columns: exact."""
+    slabs = G[:, c0:c0 + 104 * N].reshape(G.shape[0], N, 104)
+    assert len(_ZERO) == 58
+    assert (slabs[:, :, _ZERO] == 0.0).all()
+    assert (slabs[:, :, _ONE] == 1.0).all()
+    assert (slabs[:, :, _MINUS_ONE] == -1.0).all()
+    assert (slabs[:, :, 87] == -x[:, :1]).all() and (slabs[:, :, 101] == -x[:, :1]).all()
+    node = x[:, 1:].reshape(x.shape[0], N + 1, 11)
+    assert (slabs[:, :, 78] == -node[:, :N, 8]).all()      # d defect_phi / d dt = -phidot
+    assert (slabs[:, :, 91] == -node[:, :N, 9]).all()      # d defect_CL  / d dt = -CLdot
+
+
+def test_config2_single_trajectory_s10_tempest_200(tolfg, oracle):
+    p = tolfg.Problem("S10", "tempest", ts=200)
+    o = oracle.Problem("S10", "tempest", N=200)
+    for seed in (7, 8, 9):
+        x = oracle.perturbed(o, seed)
+        F, G, st = p.define_fg(x)
+        Fo, Go = o.eval(x)
+        assert st == 1
+        assert_close(F, Fo, what="cfg2 F")
+        assert_close(G, Go, mask=o.undefined_mask(), what="cfg2 G")
+        check_exact_structure(G[None, :], o.c0, 200, x[None, :])
+    p.close()
+
+
+def test_config3_single_trajectory_s10_skywalker_2000(tolfg, oracle):
+    N = 2000
+    p = tolfg.Problem("S10", "skywalker", ts=N)
+    o = oracle.Problem("S10", "skywalker", N=N)
+    assert (p.n, p.neF, p.neG) == (22012, 16012, 214037)          # SURVEY.md section 8, probed
+    for x in (o.x0(), oracle.perturbed(o, 7)):
+        F, G, st = p.define_fg(x)
+        Fo, Go = o.eval(x)
+        assert st == 1
+        assert_close(F, Fo, what="cfg3 F")
+        assert_close(G, Go, mask=o.undefined_mask(), what="cfg3 G")
+        check_exact_structure(G[None, :], o.c0, N, x[None, :])
+    # defects are affine in the next node's state with unit slope: moving x_{k+1,r} by d moves defect r of node k by d
+    x = oracle.perturbed(o, 3)
+    F0 = p.define_fg(x, needG=False)[0]
+    x2 = x.copy()
+    k, r, d = 1234, 4, 0.5
+    x2[11 * (k + 1) + 1 + r] += d
+    F1 = p.define_fg(x2, needG=False)[0]
+    assert F1[8 * k + 1 + r] - F0[8 * k + 1 + r] == pytest.approx(d, abs=1e-12)
+    p.close()
+
+
+def _batch_inputs(tolfg, oracle, mission, B, N, seed, n_aircraft=1):
+    rng = np.random.default_rng(seed)
+    trajs = []
+    for t in range(B):
+        trajs.append(tolfg.Trajectory(aircraft=t % n_aircraft, Vref=rng.uniform(0, 5), href=rng.uniform(5, 20),
+                                      radius_goal=100.0 if mission == "S10" else 0.0,
+                                      xi=rng.uniform(-50, 50), yi=rng.uniform(-50, 50)))
+    return trajs, rng.uniform(-100, -20, B)
+
+
+def _oracle_for(oracle, mission, tr, zi, N):
+    return oracle.Problem(mission, AIRCRAFT[tr.aircraft], N=N, east_goal=tr.east_goal, north_goal=tr.north_goal,
+                          radius_goal=tr.radius_goal, start=(tr.xi, tr.yi, zi), Vref=tr.Vref, href=tr.href)
+
+
+def test_config4_batch_1024_s10_randomised_wind_and_start(tolfg, oracle):
+    import torch
+    B, N = 1024, 200
+    bt = tolfg.Batch("S10", ["tempest"], ts=N)
+    trajs, zis = _batch_inputs(tolfg, oracle, "S10", B, N, 1000)
+    bt.set_trajectories(trajs)
+    X = np.empty((B, bt.n))
+    for t in range(B):
+        rng = np.random.default_rng(5000 + t)
+        x = bt.x0(t, zi=zis[t])
+        X[t] = x + 0.05 * rng.uniform(-1, 1, x.shape) * (1 + np.abs(x))
+        X[t, 0] = abs(X[t, 0]) + 0.01
+    dX, dF, dG = bt.alloc(B)
+    dX[:, :bt.n] = torch.from_numpy(X).cuda()
+    obj = torch.empty(B, dtype=torch.float64, device="cuda")
+    bt.eval(dX, dF, dG, obj=obj)
+    torch.cuda.synchronize()
+    F, G = dF[:, :bt.neF].cpu().numpy(), dG[:, :bt.neG].cpu().numpy()
+    assert np.array_equal(obj.cpu().numpy(), F[:, 0])
+    worst = 0.0
+    for t in range(B):                       # the whole batch against the oracle
+        o = _oracle_for(oracle, "S10", trajs[t], zis[t], N)
+        Fo, Go = o.eval(X[t])
+        worst = max(worst, assert_close(F[t], Fo, what=f"cfg4 F[{t}]"),
+                    assert_close(G[t], Go, mask=o.undefined_mask(), what=f"cfg4 G[{t}]"))
+    check_exact_structure(G, 3 * N + 4, N, X)
+    # periodic boundary rows are plain differences: exact
+    want = X[:, 11 * N + 1:11 * N + 12] - X[:, 1:12]
+    want[:, 5] -= 2 * np.pi
+    assert np.array_equal(F[:, 8 * N + 1:], want)
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_config5_mixed_missions_all_airframes_8192(tolfg, oracle, dtype):
+    import torch
+    N, Bm = 200, 4096                        # 4096 S10 + 4096 G7 = 8192 trajectories
+    tol = 1e-12 if dtype == "f64" else 2e-3
+    for mission in ("S10", "G7"):
+        bt = tolfg.Batch(mission, AIRCRAFT, ts=N, dtype=dtype)
+        trajs, zis = _batch_inputs(tolfg, oracle, mission, Bm, N, 77, n_aircraft=5)
+        bt.set_trajectories(trajs)
+        X = np.empty((Bm, bt.n))
+        for t in range(Bm):
+            rng = np.random.default_rng(9000 + t)
+            x = bt.x0(t, zi=zis[t])
+            X[t] = x + 0.05 * rng.uniform(-1, 1, x.shape) * (1 + np.abs(x))
+            X[t, 0] = abs(X[t, 0]) + 0.01
+        dX, dF, dG = bt.alloc(Bm)
+        dX[:, :bt.n] = torch.from_numpy(X).to(bt.torch_dtype()).cuda()
+        bt.eval(dX, dF, dG)
+        torch.cuda.synchronize()
+        Xs = dX[:, :bt.n].double().cpu().numpy()
+        F, G = dF[:, :bt.neF].double().cpu().numpy(), dG[:, :bt.neG].double().cpu().numpy()
+        assert np.isfinite(F).all() and np.isfinite(G).all()
+        c0 = 3 * N + 4 if mission == "S10" else N + 6
+        check_exact_structure(G, c0, N, Xs)
+        for t in range(0, Bm, 32):           # every 32nd trajectory against the oracle
+            o = _oracle_for(oracle, mission, trajs[t], zis[t], N)
+            Fo, Go = o.eval(Xs[t])
+            assert_close(F[t], Fo, tol=tol, what=f"cfg5 {mission} F[{t}]")
+            assert_close(G[t], Go, tol=tol, mask=o.undefined_mask(), what=f"cfg5 {mission} G[{t}]")
+
+
+@pytest.mark.parametrize("B", [1, 3, 8, 9])
+@pytest.mark.parametrize("N", [1, 4, 5, 64, 68])
+def test_ragged_batches_and_tile_edges(tolfg, oracle, B, N):
+    import torch
+    bt = tolfg.Batch("G7", ["tempest", "skywalker"], ts=N)
+    trajs = [tolfg.Trajectory(aircraft=t % 2, radius_goal=0.0, Vref=1.0 + t, href=9.0) for t in range(B)]
+    bt.set_trajectories(trajs)
+    ops = [oracle.Problem("G7", ("tempest", "skywalker")[t % 2], N=N, radius_goal=0.0, Vref=1.0 + t, href=9.0) for t in range(B)]
+    X = np.stack([oracle.perturbed(ops[t], 40 + t) for t in range(B)])
+    dX, dF, dG = bt.alloc(B)
+    dX[:, :bt.n] = torch.from_numpy(X).cuda()
+    dF.fill_(float("nan")); dG.fill_(float("nan"))
+    bt.eval(dX, dF, dG)
+    torch.cuda.synchronize()
+    for t in range(B):
+        Fo, Go = ops[t].eval(X[t])
+        assert_close(dF[t, :bt.neF].cpu().numpy(), Fo, what=f"ragged F[{t}]")
+        assert_close(dG[t, :bt.neG].cpu().numpy(), Go, what=f"ragged G[{t}]")

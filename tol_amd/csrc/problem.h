@@ -134,6 +134,8 @@ private:
     double *dX_ = nullptr, *dF_ = nullptr, *dG_ = nullptr, *dW_ = nullptr;
     long ldx_, ldf_, ldg_;
     bool device_ready_ = false, staged_ = false, haveF_ = false, haveG_ = false;
+    size_t zero_copy_limit_ = 512u << 10;   // bytes of x+F+G up to which the kernels address host memory directly
+    bool zero_copy_ = true;           // TOLFG_CALLBACK_STAGING=1 selects explicit H2D/D2H copies instead
 };
 
 // ref: class problemS10 / problemG7 -- the two missions on the path
