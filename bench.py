@@ -107,6 +107,34 @@ def callback_mode(tol_amd, mission, aircraft, ts, calls):
             "us_per_call": 1e6 * dt / calls, "node_evals_per_s": calls * ts / dt, "calls": calls}
 
 
+def compact_side_run(tol_amd, torch, args, dX, B, steps=50):
+    """SURVEY.md section 8(f) rank 1, measured beside the headline: the same batch through the compact
+    sparsity pattern (46 instead of 104 entries per node).  Not the headline metric -- it changes
+    the pattern handed to SNOPT."""
+    bc = tol_amd.Batch(args.mission, (args.aircraft,), ts=args.ts, dtype=args.dtype, device=dX.device.index,
+                       pattern="compact")
+    # same trajectories as the headline batch
+    import ctypes as C
+    from tol_amd import capi
+    make_inputs(bc, tol_amd, B, first_index=0)
+    _, dF, dG = bc.alloc(B)
+    obj = torch.empty(B, dtype=dF.dtype, device=dF.device)
+    for _ in range(5):
+        bc.eval(dX, dF, dG, obj=obj)
+    torch.cuda.synchronize()
+    bc.set_timing(True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        bc.eval(dX, dF, dG, obj=obj)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    _, kms, _ = bc.kernel_time()
+    alg = bc.algorithmic_bytes(B)
+    return {"value": B * args.ts * steps / dt, "unit": "node-evals/s", "steps": steps, "ms_per_step": 1e3 * dt / steps,
+            "kernel_ms": kms, "algorithmic_bytes_per_launch": alg, "achieved_GBs": alg / (kms * 1e-3) / 1e9,
+            "frac_of_hbm_peak": alg / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, "bytes_per_node": alg / (B * args.ts)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -120,6 +148,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-callback", action="store_true")
+    ap.add_argument("--pattern", default="reference", choices=["reference", "compact"],
+                    help="Jacobian sparsity pattern; the headline metric is quoted on the reference's own pattern")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N > 1; gloo (objectives staged through host memory) only "
                          "rehearses the multi-rank step loop when several ranks must share one GPU")
@@ -149,7 +179,7 @@ def main():
             dist.init_process_group("gloo")
 
     B = args.batch
-    bt = tol_amd.Batch(args.mission, (args.aircraft,), ts=args.ts, dtype=args.dtype, device=local)
+    bt = tol_amd.Batch(args.mission, (args.aircraft,), ts=args.ts, dtype=args.dtype, device=local, pattern=args.pattern)
     _, X = make_inputs(bt, tol_amd, B, first_index=rank * B)
     dX, dF, dG = bt.alloc(B)
     dX[:, :bt.n] = torch.from_numpy(X).to(bt.torch_dtype()).cuda()
@@ -227,7 +257,7 @@ def main():
             "config": {"workload": f"problem{args.mission}/{args.aircraft}.param/ts={args.ts} (BASELINE configs[1]) as a "
                                    f"device-resident batch of {B} trajectories per GPU with randomized shear wind and "
                                    f"start offsets (configs[3] recipe); one fused F+G launch + objective gather per step",
-                       "mission": args.mission, "aircraft": args.aircraft, "ts": args.ts,
+                       "mission": args.mission, "aircraft": args.aircraft, "ts": args.ts, "pattern": args.pattern,
                        "batch_per_gpu": B, "global_batch": B * world,
                        "parallelism": f"batch-sharded x{world}, RCCL all-gather of objectives" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -237,6 +267,8 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
+        if world == 1 and args.pattern == "reference" and not args.no_callback:
+            line["next_compact_pattern"] = compact_side_run(tol_amd, torch, args, dX, B)
         if world == 1 and not args.no_callback:
             line["callback"] = [callback_mode(tol_amd, "S10", "tempest", 200, 300),
                                 callback_mode(tol_amd, "S10", "skywalker", 2000, 100)]

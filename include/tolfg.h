@@ -45,6 +45,14 @@ enum {
 
 enum { TOLFG_F64 = 0, TOLFG_F32 = 1 };
 
+/* Jacobian sparsity pattern handed to SNOPT.
+ * REFERENCE: exactly what problem::countG builds (src/problem.cpp:813-919), 104 entries per node of
+ *            which 58 are structural zeros -- the drop-in choice and the default.
+ * COMPACT:   the same rows without entries that are zero for every x (46 per node, and no dt entries
+ *            in the boundary rows): 1.85x fewer bytes per evaluation.  Any driver that takes the
+ *            pattern from tolfg_pattern() can use it; values of the kept entries are identical. */
+enum { TOLFG_PATTERN_REFERENCE = 0, TOLFG_PATTERN_COMPACT = 1 };
+
 /* ------------------------------------------------------------------ 2. problem set-up */
 
 /* What the reference takes from argv (ref: arguments::arguments(char**), src/arguments.cpp:32-46)
@@ -65,6 +73,7 @@ typedef struct tolfg_config {
     int    device;            /* HIP device ordinal                                                */
     int    debug_dumps;       /* 1 = also rewrite Xoutput/Foutput/Goutput.txt each call like the
                                  reference does (src/DefineFG.cpp:16-46); default 0                */
+    int    pattern;           /* TOLFG_PATTERN_*; default REFERENCE                                */
 } tolfg_config;
 
 void tolfg_config_default(tolfg_config *cfg);
@@ -144,6 +153,7 @@ typedef struct tolfg_batch_config {
     int                windmodel;
     int                dtype;         /* TOLFG_F64 | TOLFG_F32: element type of X, F, G, wind      */
     int                device;
+    int                pattern;       /* TOLFG_PATTERN_*; default REFERENCE                        */
 } tolfg_batch_config;
 
 typedef struct tolfg_batch tolfg_batch;
@@ -182,7 +192,7 @@ int  tolfg_batch_set_timing(tolfg_batch *b, int enable);
 int  tolfg_batch_kernel_time(tolfg_batch *b, double *avg_ms, double *min_ms);
 
 /* algorithmic bytes one evaluation of B trajectories moves: elemsize * B * (n + neF + neG)
- *  */
+ * (SURVEY.md section 8d), with neG of the batch's pattern */
 double tolfg_batch_algorithmic_bytes(const tolfg_batch *b, int B);
 
 /* ------------------------------------------------------------------ misc */

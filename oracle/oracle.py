@@ -207,6 +207,35 @@ class Problem:
         return m
 
 
+# tabG indices (0..10 = node variables, 11 = dt) each dynamics row of the reference assigns
+# (src/problem.cpp:1080-1186); everything else in a row stays at its initial 0.0 for every x.
+ASSIGNED_TABG = {1: (0, 3, 4, 5, 11), 2: (1, 3, 4, 5, 11), 3: (2, 3, 4, 11), 4: (3, 4, 5, 7, 10, 11),
+                 5: (3, 4, 5, 6, 7, 11), 6: (3, 4, 5, 6, 7, 11), 7: (6, 8, 11), 8: (7, 9, 11)}
+
+
+def compact_index(problem):
+    """Indices into the reference-pattern G of the entries that are not structurally zero: per node
+    the 46 entries the reference's dynamicsGradients can make non-zero (38 assigned + 8 next-node
+    ones), the whole objective row, and the boundary rows without their dt column."""
+    iG, jG = problem.pattern()
+    N = problem.N
+    keep = np.ones(problem.neG, dtype=bool)
+    for e in range(problem.neG):
+        row, col = int(iG[e]), int(jG[e])
+        if 1 <= row <= 8 * N:
+            k, r = (row - 1) // 8, (row - 1) % 8 + 1
+            if col == 0:
+                m = 11
+            elif col >= 11 * (k + 1) + 1:
+                continue                      # next-node entry, always 1.0
+            else:
+                m = col - (11 * k + 1)
+            keep[e] = m in ASSIGNED_TABG[r]
+        elif row > 8 * N:
+            keep[e] = col != 0
+    return np.flatnonzero(keep)
+
+
 def eval_batch(problems, X, nthreads=1, opt="O2"):
     """Evaluate a list of oracle Problems (same mission and N) on the rows of X."""
     B = len(problems)

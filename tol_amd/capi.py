@@ -7,6 +7,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 OK, ERR_ARG, ERR_PARAM, ERR_HIP, ERR_NOCURRENT = 0, -1, -2, -3, -4
 WIND_NONE, WIND_SHEAR, WIND_TABLE = 0, 1, 99
 F64, F32 = 0, 1
+PATTERN_REFERENCE, PATTERN_COMPACT = 0, 1
+PATTERNS = {"reference": 0, "compact": 1}
 IU_MAGIC = 0x70F6
 
 _dp = C.POINTER(C.c_double)
@@ -27,7 +29,7 @@ class Config(C.Structure):
                 ("ts", C.c_int), ("windmodel", C.c_int),
                 ("Vref", C.c_double), ("href", C.c_double),
                 ("xi", C.c_double), ("yi", C.c_double), ("zi", C.c_double),
-                ("device", C.c_int), ("debug_dumps", C.c_int)]
+                ("device", C.c_int), ("debug_dumps", C.c_int), ("pattern", C.c_int)]
 
 
 class Traj(C.Structure):
@@ -40,7 +42,8 @@ class Traj(C.Structure):
 class BatchConfig(C.Structure):
     _fields_ = [("mission", C.c_char_p), ("root_path", C.c_char_p),
                 ("aircraft", C.POINTER(C.c_char_p)), ("n_aircraft", C.c_int),
-                ("ts", C.c_int), ("windmodel", C.c_int), ("dtype", C.c_int), ("device", C.c_int)]
+                ("ts", C.c_int), ("windmodel", C.c_int), ("dtype", C.c_int), ("device", C.c_int),
+                ("pattern", C.c_int)]
 
 
 # snFunA, include/snopt/snopt.h:60-66 of the reference

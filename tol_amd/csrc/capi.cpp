@@ -242,7 +242,8 @@ int tolfg_batch_create(const tolfg_batch_config *cfg, tolfg_batch **out)
             names.emplace_back(cfg->aircraft[i]);
         }
         const std::string root = cfg->root_path ? std::string(cfg->root_path) : default_root();
-        *out = new tolfg_batch{new batch(cfg->mission, root, names, cfg->ts, cfg->windmodel, cfg->dtype, cfg->device)};
+        *out = new tolfg_batch{new batch(cfg->mission, root, names, cfg->ts, cfg->windmodel, cfg->dtype, cfg->device,
+                                        cfg->pattern)};
     });
 }
 

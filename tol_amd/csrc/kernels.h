@@ -9,6 +9,7 @@ namespace tolfg {
 enum { MISSION_S10 = 0, MISSION_G7 = 1 };
 enum { WIND_NONE = 0, WIND_SHEAR = 1, WIND_TABLE = 2 };   // kernel-side enumeration
 enum { MAX_AIRCRAFT = 8 };
+enum { PATTERN_REFERENCE = 0, PATTERN_COMPACT = 1 };   // slab_table.h
 
 // Air-frame constants as the kernels want them (reciprocals taken once on the host).
 // ref: the members of `aircraft` the path reads, include/parameters.h:25-30, and g/rho,
@@ -38,6 +39,7 @@ struct FgArgs {
     int  B, N, c0;
     int  tiles, nt;        // tiles per trajectory and nodes per tile, from plan_tiles()
     int  needF, needG;
+    int  pattern;          // PATTERN_REFERENCE (104-entry slabs) | PATTERN_COMPACT (46-entry slabs)
     double *partial;       // [B*tiles][2] objective partials (sum T^2, sum (r-R)^2), device
     void   *obj;           // optional [B]: finalize_kernel also writes the objectives here, contiguous
     double kT, kp, kv, kdt;

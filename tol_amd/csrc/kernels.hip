@@ -30,6 +30,7 @@
 // The maths is the vector form stated in oracle/tolfg_oracle.c; W and grad W are held constant in
 // the Jacobian exactly as the reference's tabulated entries do.
 #include "kernels.h"
+#include "slab_table.h"
 
 #include <hip/hip_runtime.h>
 
@@ -45,35 +46,16 @@ constexpr int TILE = 64;           // nodes per dynamics tile = wavefront width
 #define TOLFG_MIN_WAVES_PER_SIMD 2  // register budget 256: the fp64 tile needs ~190 live values
 #endif
 constexpr int NI = 11;             // variables per node   (problems/*/snopt.param:3)
-constexpr int SLAB = 104;          // 8 rows x 13 pattern entries per node
 constexpr double kGrav = 9.81;     // include/problem.h:72
 constexpr double kTwoPi = 6.283185307179586476925286766559;
 
-// LDS row of one node (elements): 32 computed Jacobian values and the 3 constants.
-constexpr int SL_ZERO = 32, SL_ONE = 33, SL_MONE = 34;
+// LDS row of one node (elements): 32 computed Jacobian values and the 3 constants (slab_table.h).
 constexpr int RS = 35;             // odd stride: conflict-free ds_write_b64 across lanes
 
-// ---- which LDS slot feeds slab element e = 13*(row-1) + col,  col = [dt | x y z Va gam chi phi CL dphi dCL T | next]
-struct SlabTable { unsigned char c[SLAB]; };
-constexpr SlabTable make_slab_table()
-{
-    SlabTable t{};
-    for (int i = 0; i < SLAB; i++) t.c[i] = SL_ZERO;
-    for (int r = 0; r < 8; r++) t.c[13 * r + 12] = SL_ONE;          // d defect_r / d s_{k+1,r}
-    // row 1 (x)                          row 2 (y)                           row 3 (z)
-    t.c[0] = 0;  t.c[1] = SL_MONE;        t.c[13] = 4; t.c[15] = SL_MONE;     t.c[26] = 8; t.c[29] = SL_MONE;
-    t.c[4] = 1;  t.c[5] = 2; t.c[6] = 3;  t.c[17] = 5; t.c[18] = 6; t.c[19] = 7;  t.c[30] = 9; t.c[31] = 10;
-    // row 4 (Va): dt Va gam chi CL T
-    t.c[39] = 11; t.c[43] = 12; t.c[44] = 13; t.c[45] = 14; t.c[47] = 15; t.c[50] = 16;
-    // row 5 (gam): dt Va gam chi phi CL
-    t.c[52] = 17; t.c[56] = 18; t.c[57] = 19; t.c[58] = 20; t.c[59] = 21; t.c[60] = 22;
-    // row 6 (chi): dt Va gam chi phi CL
-    t.c[65] = 23; t.c[69] = 24; t.c[70] = 25; t.c[71] = 26; t.c[72] = 27; t.c[73] = 28;
-    // row 7 (phi): dt, phi = -1, dphi = -dt        row 8 (CL): dt, CL = -1, dCL = -dt
-    t.c[78] = 29; t.c[85] = SL_MONE; t.c[87] = 31;  t.c[91] = 30; t.c[99] = SL_MONE; t.c[101] = 31;
-    return t;
-}
-__device__ constexpr SlabTable kSlab = make_slab_table();
+__device__ constexpr SlabTableFull kSlabFull = make_slab_table();
+__device__ constexpr SlabTableCompact kSlabCompact = make_compact_table();
+
+constexpr int gcd_c(int a, int b) { return b == 0 ? a : gcd_c(b, a % b); }
 
 #ifdef TOLFG_STAMPS
 #define TOLFG_STAMP(a, slot)                                                                         \
@@ -224,24 +206,38 @@ template <typename T, int WIND> struct NodeCtx {
     }
 };
 
-// Stream the tile's cnt slabs (SLAB*cnt contiguous elements at gslab) out of the LDS rows.
-// Wave instruction i covers elements [64*VEC*i, 64*VEC*(i+1)); the (node, element) a lane meets
-// repeats every 13 instructions = 8*VEC nodes, so the 13 LDS offsets are formed once per kernel.
-template <typename T, int VEC> struct SlabOffsets {
-    // element offsets (< 64*RS = 2240) packed two per register to keep 26 values out of 26 VGPRs
-    unsigned pk[13][(VEC + 1) / 2];
+// Stream the tile's cnt slabs (SLABN*cnt contiguous elements at gslab) out of the LDS rows.
+// Wave instruction i covers elements [64*GV*i, 64*GV*(i+1)); the (node, element) a lane meets
+// repeats every P instructions (13 for the 104-entry slab, 23 for the 46-entry one), so the P LDS
+// offsets are formed once, packed two per register.
+template <int PAT, int GV> struct SlabGeom {
+    static constexpr int SLABN = PAT == PATTERN_COMPACT ? SLAB_COMPACT : SLAB_FULL;
+    static constexpr int PN = SLABN / GV;                      // vectors per node
+    static constexpr int NPER = gcd_c(PN, TILE);               // periods per 64-node tile
+    static constexpr int P = PN / NPER;                        // wave instructions per period
+    static constexpr int NPP = TILE / NPER;                    // nodes per period
+    static_assert(SLABN % GV == 0, "slab must be a whole number of vectors");
+};
+
+template <typename T, int PAT, int GV> struct SlabOffsets {
+    typedef SlabGeom<PAT, GV> Gm;
+    unsigned pk[Gm::P][(GV + 1) / 2];
+    __device__ __forceinline__ static int code(int e)
+    {
+        if constexpr (PAT == PATTERN_COMPACT) return kSlabCompact.c[e];
+        else return kSlabFull.c[e];
+    }
     __device__ __forceinline__ void init(int lane)
     {
-        constexpr int PN = SLAB / VEC;
 #pragma unroll
-        for (int t = 0; t < 13; t++) {
+        for (int t = 0; t < Gm::P; t++) {
             const int pp = TILE * t + lane;
-            const int nd = pp / PN;
-            const int e = (pp - nd * PN) * VEC;
+            const int nd = pp / Gm::PN;
+            const int e = (pp - nd * Gm::PN) * GV;
 #pragma unroll
-            for (int h = 0; h < (VEC + 1) / 2; h++) {
-                unsigned lo = nd * RS + kSlab.c[e + 2 * h];
-                unsigned hi = (2 * h + 1 < VEC) ? nd * RS + kSlab.c[e + 2 * h + 1] : 0u;
+            for (int h = 0; h < (GV + 1) / 2; h++) {
+                unsigned lo = nd * RS + code(e + 2 * h);
+                unsigned hi = (2 * h + 1 < GV) ? nd * RS + code(e + 2 * h + 1) : 0u;
                 pk[t][h] = lo | (hi << 16);
             }
         }
@@ -253,29 +249,27 @@ template <typename T, int VEC> struct SlabOffsets {
     }
 };
 
-template <typename T, int VEC>
-__device__ __forceinline__ void store_slabs(const T *lds, T *gslab, int cnt, int lane, const SlabOffsets<T, VEC> &so)
+template <typename T, int PAT, int GV>
+__device__ __forceinline__ void store_slabs(const T *lds, T *gslab, int cnt, int lane, const SlabOffsets<T, PAT, GV> &so)
 {
-    typedef typename Vec<T, VEC>::type vec;
-    constexpr int PN = SLAB / VEC;       // vectors per node
-    constexpr int NPP = 8 * VEC;         // nodes per period
-    constexpr int NPER = TILE / NPP;     // periods per tile
-    const int total = PN * cnt;
+    typedef typename Vec<T, GV>::type vec;
+    typedef SlabGeom<PAT, GV> Gm;
+    const int total = Gm::PN * cnt;
 #pragma unroll 1
-    for (int j = 0; j < NPER; j++) {
-        if (j * NPP >= cnt) break;       // wave-uniform
-        const T *grp = lds + j * NPP * RS;
+    for (int j = 0; j < Gm::NPER; j++) {
+        if (j * Gm::NPP >= cnt) break;   // wave-uniform
+        const T *grp = lds + j * Gm::NPP * RS;
 #pragma unroll
-        for (int t = 0; t < 13; t++) {
-            const int p = TILE * (13 * j + t) + lane;
+        for (int t = 0; t < Gm::P; t++) {
+            const int p = TILE * (Gm::P * j + t) + lane;
             if (p < total) {
-                if constexpr (VEC == 1) {
+                if constexpr (GV == 1) {
                     stream_store(gslab + p, grp[so.off(t, 0)]);
                 } else {
                     vec val;
 #pragma unroll
-                    for (int v = 0; v < VEC; v++) val[v] = grp[so.off(t, v)];
-                    stream_store(reinterpret_cast<vec *>(gslab + (long)p * VEC), val);
+                    for (int v = 0; v < GV; v++) val[v] = grp[so.off(t, v)];
+                    stream_store(reinterpret_cast<vec *>(gslab + (long)p * GV), val);
                 }
             }
         }
@@ -307,10 +301,13 @@ __device__ __forceinline__ void store_defects(T *p, const T (&d)[8])
     }
 }
 
-template <typename T, int MISSION, int WIND, int VEC>
+template <typename T, int MISSION, int WIND, int VEC, int PAT>
 __global__ __launch_bounds__(TILE, TOLFG_MIN_WAVES_PER_SIMD) void fg_kernel(const FgArgs a)
 {
     typedef typename Vec<T, VEC>::type vec;
+    // slab stores: 16 bytes per lane where the slab length allows (46 floats are 23 pairs, not quads)
+    constexpr int GV = (PAT == PATTERN_COMPACT && VEC == 4) ? 2 : VEC;
+    constexpr int SLABN = SlabGeom<PAT, GV>::SLABN;
     constexpr int NW = ((NI * TILE + 9 + VEC - 1) / VEC + TILE - 1) / TILE;   // window vectors per lane
     __shared__ __attribute__((aligned(16))) T lds[TILE * RS];
     const int lane = threadIdx.x;
@@ -426,9 +423,9 @@ __global__ __launch_bounds__(TILE, TOLFG_MIN_WAVES_PER_SIMD) void fg_kernel(cons
         __syncthreads();
         TOLFG_STAMP(a, 3);
         __builtin_amdgcn_sched_barrier(0);
-        SlabOffsets<T, VEC> so;
+        SlabOffsets<T, PAT, GV> so;
         so.init(lane);
-        if (!(TOLFG_VARIANT(a) & 2048)) store_slabs<T, VEC>(lds, Grow + a.c0 + (long)SLAB * k0, cnt, lane, so);
+        if (!(TOLFG_VARIANT(a) & 2048)) store_slabs<T, PAT, GV>(lds, Grow + a.c0 + (long)SLABN * k0, cnt, lane, so);
         TOLFG_STAMP(a, 4);
     }
     TOLFG_STAMP(a, 5);
@@ -442,9 +439,10 @@ __global__ __launch_bounds__(TILE, TOLFG_MIN_WAVES_PER_SIMD) void fg_kernel(cons
 // One wavefront per trajectory, lanes = output entries: objective value, the last node's
 // objective-gradient entries, boundary rows and their gradients.  O(1) per trajectory except the
 // in-order sum over the tiles' objective partials (deterministic, no atomics).
-template <typename T, int MISSION>
+template <typename T, int MISSION, int PAT>
 __global__ __launch_bounds__(TILE) void finalize_kernel(const FgArgs a)
 {
+    constexpr int SLABN = PAT == PATTERN_COMPACT ? SLAB_COMPACT : SLAB_FULL;
     const int b = blockIdx.x;
     const int lane = threadIdx.x;
     const int N = a.N;
@@ -455,7 +453,7 @@ __global__ __launch_bounds__(TILE) void finalize_kernel(const FgArgs a)
     const T dt = x[0];
     const T kT = T(a.kT), kp = T(a.kp);
     const T TN = x[NI * N + 11];
-    const long gb = a.c0 + (long)SLAB * N;          // first boundary-row entry
+    const long gb = a.c0 + (long)SLABN * N;         // first boundary-row entry
 
     T sumT = T(0), sumP = T(0);
     if (a.needF) {
@@ -488,8 +486,10 @@ __global__ __launch_bounds__(TILE) void finalize_kernel(const FgArgs a)
             if (lane == 0) G[0] = T(a.kdt);
             if (lane < 3) G[1 + 3 * N + lane] = lane == 0 ? kp * d * dx / r : (lane == 1 ? kp * d * dy / r : kT * TN);
             // rows [dt, node 0, node N] = [0, -1, +1]; the dt entry is undefined in the
-            // reference (src/problemS10.cpp:397), defined as 0 here
-            if (lane < 33) {
+            // reference (src/problemS10.cpp:397), defined as 0 here and dropped by the compact pattern
+            if constexpr (PAT == PATTERN_COMPACT) {
+                if (lane < 22) G[gb + lane] = (lane & 1) ? T(1) : T(-1);
+            } else if (lane < 33) {
                 const int c = lane % 3;
                 G[gb + lane] = c == 0 ? T(0) : (c == 1 ? T(-1) : T(1));
             }
@@ -529,12 +529,15 @@ __global__ __launch_bounds__(TILE) void finalize_kernel(const FgArgs a)
                 else                { v = kT * TN;                          idx = N + 5; }
                 G[idx] = v;
             }
-            // boundary rows: 5 + 5 + 9*3 + 5 = 42 entries  (src/problemG7.cpp:407-511)
+            // boundary rows: 5 + 5 + 9*3 + 5 = 42 entries  (src/problemG7.cpp:407-511); the compact
+            // pattern drops each row's dt entry (always 0): 4 + 4 + 9*2 + 4 = 30
             if (lane < 42) {
                 const T ux = dxf / dist, uy = dyf / dist;
                 T v;
+                int c, pos;                          // c: 0 = dt column; pos: index in the compact layout
                 if (lane < 10) {
-                    const int c = lane % 5;          // [dt, x0, y0, xN, yN]
+                    c = lane % 5;                    // [dt, x0, y0, xN, yN]
+                    pos = 4 * (lane / 5) + c - 1;
                     const T trig = lane < 5 ? cchi : schi;
                     const int diag = lane < 5 ? 1 : 2;
                     if (c == 0) v = T(0);
@@ -544,13 +547,19 @@ __global__ __launch_bounds__(TILE) void finalize_kernel(const FgArgs a)
                         v = c <= 2 ? g0 : -g0;
                     }
                 } else if (lane < 37) {
-                    const int c = (lane - 10) % 3;
+                    c = (lane - 10) % 3;
+                    pos = 8 + 2 * ((lane - 10) / 3) + c - 1;
                     v = c == 0 ? T(0) : (c == 1 ? T(-1) : T(1));
                 } else {
-                    const int c = lane - 37;         // [dt, x0, y0, xN, yN] of dist - dmax
+                    c = lane - 37;                   // [dt, x0, y0, xN, yN] of dist - dmax
+                    pos = 26 + c - 1;
                     v = c == 0 ? T(0) : (c == 1 ? -ux : (c == 2 ? -uy : (c == 3 ? ux : uy)));
                 }
-                G[gb + lane] = v;
+                if constexpr (PAT == PATTERN_COMPACT) {
+                    if (c != 0) G[gb + pos] = v;
+                } else {
+                    G[gb + lane] = v;
+                }
             }
         }
     }
@@ -563,30 +572,38 @@ __global__ void objectives_kernel(const T *F, long ldf, T *obj, int B)
     if (t < B) obj[t] = F[(long)t * ldf];
 }
 
-template <typename T, int MISSION, int WIND>
+template <typename T, int MISSION, int WIND, int PAT>
 hipError_t launch_vec(const FgArgs &a, int vec, dim3 grid, hipStream_t s, hipEvent_t t0, hipEvent_t t1)
 {
     constexpr int VMAX = 16 / sizeof(T);
     hipError_t e;
     if (t0 && (e = hipEventRecord(t0, s)) != hipSuccess) return e;
-    if (vec == VMAX) hipLaunchKernelGGL((fg_kernel<T, MISSION, WIND, VMAX>), grid, dim3(TILE), 0, s, a);
-    else             hipLaunchKernelGGL((fg_kernel<T, MISSION, WIND, 1>), grid, dim3(TILE), 0, s, a);
+    if (vec == VMAX) hipLaunchKernelGGL((fg_kernel<T, MISSION, WIND, VMAX, PAT>), grid, dim3(TILE), 0, s, a);
+    else             hipLaunchKernelGGL((fg_kernel<T, MISSION, WIND, 1, PAT>), grid, dim3(TILE), 0, s, a);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (t1 && (e = hipEventRecord(t1, s)) != hipSuccess) return e;
-    hipLaunchKernelGGL((finalize_kernel<T, MISSION>), dim3(a.B), dim3(TILE), 0, s, a);
+    hipLaunchKernelGGL((finalize_kernel<T, MISSION, PAT>), dim3(a.B), dim3(TILE), 0, s, a);
     return hipGetLastError();
 }
 
-template <typename T, int MISSION>
+template <typename T, int MISSION, int PAT>
 hipError_t launch_wind(const FgArgs &a, int wind, int vec, dim3 grid, hipStream_t s, hipEvent_t t0, hipEvent_t t1)
 {
     switch (wind) {
-    case WIND_NONE:  return launch_vec<T, MISSION, WIND_NONE>(a, vec, grid, s, t0, t1);
-    case WIND_SHEAR: return launch_vec<T, MISSION, WIND_SHEAR>(a, vec, grid, s, t0, t1);
-    case WIND_TABLE: return launch_vec<T, MISSION, WIND_TABLE>(a, vec, grid, s, t0, t1);
+    case WIND_NONE:  return launch_vec<T, MISSION, WIND_NONE, PAT>(a, vec, grid, s, t0, t1);
+    case WIND_SHEAR: return launch_vec<T, MISSION, WIND_SHEAR, PAT>(a, vec, grid, s, t0, t1);
+    case WIND_TABLE: return launch_vec<T, MISSION, WIND_TABLE, PAT>(a, vec, grid, s, t0, t1);
     }
     return hipErrorInvalidValue;
+}
+
+template <typename T, int PAT>
+hipError_t launch_mission(const FgArgs &a, int mission, int wind, int vec, dim3 grid, hipStream_t s, hipEvent_t t0,
+                          hipEvent_t t1)
+{
+    return mission == MISSION_S10 ? launch_wind<T, MISSION_S10, PAT>(a, wind, vec, grid, s, t0, t1)
+                                  : launch_wind<T, MISSION_G7, PAT>(a, wind, vec, grid, s, t0, t1);
 }
 
 }  // namespace
@@ -614,12 +631,12 @@ hipError_t launch_fg(const FgArgs &a, int mission, int wind, int dtype, int vec,
     const long W = (long)a.B * a.tiles;
     if (W > 0x7fffffffL) return hipErrorInvalidValue;
     const dim3 grid((unsigned)W);
-    if (dtype == 0) {
-        return mission == MISSION_S10 ? launch_wind<double, MISSION_S10>(a, wind, vec, grid, s, t0, t1)
-                                      : launch_wind<double, MISSION_G7>(a, wind, vec, grid, s, t0, t1);
+    if (a.pattern == PATTERN_COMPACT) {
+        return dtype == 0 ? launch_mission<double, PATTERN_COMPACT>(a, mission, wind, vec, grid, s, t0, t1)
+                          : launch_mission<float, PATTERN_COMPACT>(a, mission, wind, vec, grid, s, t0, t1);
     }
-    return mission == MISSION_S10 ? launch_wind<float, MISSION_S10>(a, wind, vec, grid, s, t0, t1)
-                                  : launch_wind<float, MISSION_G7>(a, wind, vec, grid, s, t0, t1);
+    return dtype == 0 ? launch_mission<double, PATTERN_REFERENCE>(a, mission, wind, vec, grid, s, t0, t1)
+                      : launch_mission<float, PATTERN_REFERENCE>(a, mission, wind, vec, grid, s, t0, t1);
 }
 
 hipError_t launch_objectives(const void *F, long ldf, void *obj, int B, int dtype, hipStream_t s)

@@ -62,7 +62,7 @@ std::string default_root()
 // ------------------------------------------------------------------------------------ batch
 
 batch::batch(const std::string &mission, const std::string &root, const std::vector<std::string> &names,
-             int ts, int windmodel, int dtype, int device)
+             int ts, int windmodel, int dtype, int device, int pattern)
     : gn_(mission, root), lm_(mission, root), sn_(mission, root), windmodel_(windmodel), dtype_(dtype),
       device_(device)
 {
@@ -75,8 +75,10 @@ batch::batch(const std::string &mission, const std::string &root, const std::vec
     if (N < 1) throw std::invalid_argument("ts must be >= 1");
     if (sn_.numinp != 11 || sn_.numstates != 8 || sn_.numbounds != (mid == MISSION_S10 ? 11 : 12))
         throw std::invalid_argument("snopt.param: numinp/numstates/numbounds do not describe " + mission);
-    sz_ = make_sizes(mid, N);
+    if (pattern != PATTERN_REFERENCE && pattern != PATTERN_COMPACT) throw std::invalid_argument("pattern");
+    sz_ = make_sizes(mid, N, pattern);
 
+    args_.pattern = pattern;
     args_.N = N;
     plan_tiles(N, dtype, &args_.tiles, &args_.nt);
     args_.c0 = sz_.c0;
@@ -216,7 +218,7 @@ long even(long v) { return (v + 1) & ~1L; }
 batch *make_engine(const tolfg_config &cfg)
 {
     if (!cfg.mission || !cfg.aircraft) throw std::invalid_argument("mission and aircraft are required");
-    return new batch(cfg.mission, root_of(cfg), {cfg.aircraft}, cfg.ts, cfg.windmodel, TOLFG_F64, cfg.device);
+    return new batch(cfg.mission, root_of(cfg), {cfg.aircraft}, cfg.ts, cfg.windmodel, TOLFG_F64, cfg.device, cfg.pattern);
 }
 }  // namespace
 

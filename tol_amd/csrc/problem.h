@@ -28,7 +28,7 @@ std::string default_root();
 class batch {
 public:
     batch(const std::string &mission, const std::string &root, const std::vector<std::string> &aircraft_names,
-          int ts, int windmodel, int dtype, int device);
+          int ts, int windmodel, int dtype, int device, int pattern = 0);
     ~batch();
     batch(const batch &) = delete;
     batch &operator=(const batch &) = delete;

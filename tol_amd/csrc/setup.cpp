@@ -4,6 +4,7 @@
 #include <cmath>
 
 #include "kernels.h"
+#include "slab_table.h"
 
 namespace tolfg {
 
@@ -12,16 +13,24 @@ constexpr double kGrav = 9.81;    // ref: include/problem.h:72
 constexpr double kRho = 1.2682;   // ref: include/problem.h:73
 }
 
-Sizes make_sizes(int mission, int N)
+Sizes make_sizes(int mission, int N, int pattern)
 {
     Sizes s;
     s.mission = mission;
+    s.pattern = pattern;
     s.N = N;
     s.nb = mission == MISSION_S10 ? 11 : 12;
     s.n = 11 * (N + 1) + 1;
     s.neF = 8 * N + 1 + s.nb;
-    s.neG = mission == MISSION_S10 ? 107 * N + 37 : 105 * N + 48;
-    s.c0 = mission == MISSION_S10 ? 3 * N + 4 : N + 6;
+    s.c0 = mission == MISSION_S10 ? 3 * N + 4 : N + 6;          // objective row
+    if (pattern == PATTERN_COMPACT) {
+        // 46 entries per node; boundary rows without their (always zero) dt entries
+        s.slab = SLAB_COMPACT;
+        s.neG = s.c0 + SLAB_COMPACT * N + (mission == MISSION_S10 ? 22 : 30);
+    } else {
+        s.slab = SLAB_FULL;
+        s.neG = mission == MISSION_S10 ? 107 * N + 37 : 105 * N + 48;
+    }
     return s;
 }
 
@@ -39,17 +48,21 @@ void make_pattern(const Sizes &sz, int *iG, int *jG)
         for (int k = 0; k < N; ++k) put(0, 11 * k + 11);
         put(0, 11 * N + 1); put(0, 11 * N + 2); put(0, 11 * N + 11);
     }
-    // defect rows: 13 entries each -> one contiguous 104-entry slab per node
+    // defect rows: 13 entries each -> one contiguous 104-entry slab per node; the compact pattern
+    // keeps the entries the slab table marks as structurally non-zero (46 per node)
+    constexpr SlabTableFull table = make_slab_table();
+    const bool compact = sz.pattern == PATTERN_COMPACT;
     for (int k = 0; k < N; ++k)
-        for (int r = 1; r <= 8; ++r) {
-            put(8 * k + r, 0);
-            for (int m = 0; m < 11; ++m) put(8 * k + r, 11 * k + 1 + m);
-            put(8 * k + r, 11 * (k + 1) + r);
-        }
+        for (int r = 1; r <= 8; ++r)
+            for (int c = 0; c < 13; ++c) {
+                if (compact && table.c[13 * (r - 1) + c] == SL_ZERO) continue;
+                const int col = c == 0 ? 0 : (c == 12 ? 11 * (k + 1) + r : 11 * k + c);
+                put(8 * k + r, col);
+            }
     // boundary rows
     for (int b = 0; b < sz.nb; ++b) {
         const int row = 8 * N + 1 + b;
-        put(row, 0);
+        if (!compact) put(row, 0);
         if (sz.mission == MISSION_G7 && (b == 0 || b == 1 || b == 11)) {
             put(row, 1); put(row, 2); put(row, 11 * N + 1); put(row, 11 * N + 2);
         } else {

@@ -10,9 +10,10 @@ namespace tolfg {
 // counts, in closed form; c0 = position in G of node 0's 104-entry slab.
 struct Sizes {
     int mission;   // MISSION_S10 | MISSION_G7
-    int N, nb, n, neF, neG, c0;
+    int pattern;   // PATTERN_REFERENCE | PATTERN_COMPACT (slab_table.h)
+    int N, nb, n, neF, neG, c0, slab;
 };
-Sizes make_sizes(int mission, int N);
+Sizes make_sizes(int mission, int N, int pattern = 0);
 
 // (iGfun, jGvar), 0-based, in countG's row-major order -- generated in O(neG) instead of the
 // reference's O(neF*n) probing (83 s / 20 GB at ts = 2000).

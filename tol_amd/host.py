@@ -34,7 +34,8 @@ class Problem:
 
     def __init__(self, mission, aircraft="tempest", east=0.0, north=0.0, up=100.0, east_goal=400.0,
                  north_goal=0.0, up_goal=70.0, radius_goal=100.0, ts=0, windmodel=capi.WIND_SHEAR,
-                 Vref=2.4, href=10.0, start=(0.0, 0.0, 0.0), device=0, root_path=None, debug_dumps=False):
+                 Vref=2.4, href=10.0, start=(0.0, 0.0, 0.0), device=0, root_path=None, debug_dumps=False,
+                 pattern="reference"):
         L = lib()
         cfg = Config()
         L.tolfg_config_default(C.byref(cfg))
@@ -45,6 +46,7 @@ class Problem:
         cfg.ts, cfg.windmodel, cfg.Vref, cfg.href = int(ts), int(windmodel), Vref, href
         cfg.xi, cfg.yi, cfg.zi = start
         cfg.device, cfg.debug_dumps = int(device), int(bool(debug_dumps))
+        cfg.pattern = capi.PATTERNS[pattern]
         self._h = C.c_void_p()
         check(L.tolfg_create(C.byref(cfg), C.byref(self._h)))
         n, neF, neG = C.c_int(), C.c_int(), C.c_int()
@@ -155,7 +157,7 @@ class Batch:
     """Device-resident evaluation of B trajectories that share mission and ts (one GPU)."""
 
     def __init__(self, mission, aircraft=("tempest",), ts=0, windmodel=capi.WIND_SHEAR, dtype="f64",
-                 device=0, root_path=None):
+                 device=0, root_path=None, pattern="reference"):
         L = lib()
         names = [a.encode() for a in aircraft]
         arr = (C.c_char_p * len(names))(*names)
@@ -166,6 +168,7 @@ class Batch:
         cfg.ts, cfg.windmodel = int(ts), int(windmodel)
         cfg.dtype = capi.F64 if dtype == "f64" else capi.F32
         cfg.device = int(device)
+        cfg.pattern = capi.PATTERNS[pattern]
         self._h = C.c_void_p()
         check(L.tolfg_batch_create(C.byref(cfg), C.byref(self._h)))
         n, neF, neG = C.c_int(), C.c_int(), C.c_int()
