@@ -103,6 +103,13 @@ int tolfg_tolerances(const tolfg_problem *p, double *opt_tol, double *feas_tol);
  * (ref: include/problem.h:103).  Copied to the device; switches the problem to table wind. */
 int tolfg_set_wind_table(tolfg_problem *p, const double *wind_enu);
 
+/* Result file of one solved leg, with the keys the reference's writer emits and its consumers read
+ * (ref: problem::writeJSON, src/problem.cpp:1247-1365; msl/mission.py:208-226;
+ * matlab/@plotSNOPT/plotSNOPT.m:48-58): args, problem, FinalCost, dt, trajectory{time,x,y,z,Va,gam,
+ * chi,phi,CL,dphi,dCL,T}, aircraft{...}, gains{...}, limits{...}, snopt{...}.  x is the solved
+ * decision vector (n values), final_cost the objective F[0] SNOPT ended with. */
+int tolfg_write_json(const tolfg_problem *p, const double *x, double final_cost, const char *filename);
+
 /* ------------------------------------------------------------------ 1. the SNOPT callback */
 
 /* ref: `problem *prob` global, src/tol.cpp:3 / include/global_objects.h:5.  The callback evaluates

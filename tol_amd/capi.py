@@ -64,6 +64,7 @@ SYMBOLS = {
     "tolfg_bounds": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _dp]),
     "tolfg_tolerances": (C.c_int, [C.c_void_p, _dp, _dp]),
     "tolfg_set_wind_table": (C.c_int, [C.c_void_p, _dp]),
+    "tolfg_write_json": (C.c_int, [C.c_void_p, _dp, C.c_double, C.c_char_p]),
     "tolfg_set_current": (None, [C.c_void_p]),
     "tolfg_get_current": (C.c_void_p, []),
     "tolfg_handle_index": (C.c_int, [C.c_void_p]),

@@ -172,6 +172,12 @@ int tolfg_set_wind_table(tolfg_problem *h, const double *wind_enu)
     return guarded([&] { h->p->set_wind_table(wind_enu); });
 }
 
+int tolfg_write_json(const tolfg_problem *h, const double *x, double final_cost, const char *filename)
+{
+    if (!h || !x || !filename) return fail(TOLFG_ERR_ARG, "null argument");
+    return guarded([&] { h->p->writeJSON(filename, x, final_cost); });
+}
+
 void tolfg_set_current(tolfg_problem *h)
 {
     std::lock_guard<std::mutex> lk(g_reg_mu);

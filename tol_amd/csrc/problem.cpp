@@ -361,6 +361,63 @@ void problem::computeG(const double xin[], double G[])
     collect(false, nullptr, true, G);
 }
 
+void problem::writeJSON(const std::string &filename, const double *xs, double final_cost) const
+{
+    // Keys and nesting as the reference's writer produces them (src/problem.cpp:1293-1357); numbers
+    // with 17 significant digits so that a reader recovers every double exactly.
+    FILE *fp = std::fopen(filename.c_str(), "w");
+    if (!fp) throw std::invalid_argument("cannot open " + filename);
+    const int N = eng_->sizes().N;
+    auto num = [&](double v) { std::fprintf(fp, "%.17g", v); };
+    auto key = [&](const char *k, int indent) { std::fprintf(fp, "%*s\"%s\" : ", indent, "", k); };
+    auto field = [&](const char *k, double v, bool last, int indent = 6) { key(k, indent); num(v); std::fprintf(fp, last ? "\n" : ",\n"); };
+    std::fprintf(fp, "{\n");
+    key("FinalCost", 3); num(final_cost); std::fprintf(fp, ",\n");
+    key("aircraft", 3); std::fprintf(fp, "{\n");
+    field("AR", ac.AR, false); field("CLmax", ac.CLmax, false); field("CLmin", ac.CLmin, false); field("Cd0", ac.Cd0, false);
+    field("S", ac.SS, false); field("Tmax", ac.Tmax, false); field("Tmin", ac.Tmin, false); field("Vamax", ac.Vamax, false);
+    field("Vamin", ac.Vamin, false); field("b", ac.b, false); field("dphimax", ac.phidotmax, false); field("e", ac.ee, false);
+    field("gammamax", ac.gammamax, false); field("mass", ac.mm, false);
+    key("name", 6); std::fprintf(fp, "\"%s\",\n", aircraft_type.c_str());
+    field("phimax", ac.phimax, true);
+    std::fprintf(fp, "   },\n");
+    key("args", 3); std::fprintf(fp, "{\n");
+    key("aircraft", 6); std::fprintf(fp, "\"%s\",\n", aircraft_type.c_str());
+    field("east", east, false); field("north", north, false);
+    key("problem", 6); std::fprintf(fp, "\"%s\",\n", mission.c_str());
+    field("rd", rg, false); field("up", up, false); field("xg", xg, false); field("yg", yg, false); field("zg", zg, true);
+    std::fprintf(fp, "   },\n");
+    key("dt", 3); num(xs[0]); std::fprintf(fp, ",\n");
+    key("gains", 3); std::fprintf(fp, "{\n");
+    field("kT", gn.kT, false); field("ka", gn.ka, false); field("kdt", gn.kdt, false); field("kp", gn.kp, false); field("kv", gn.kv, true);
+    std::fprintf(fp, "   },\n");
+    key("limits", 3); std::fprintf(fp, "{\n");
+    field("dtmax", lm.dtmax, false); field("dtmin", lm.dtmin, false); field("xmax", lm.xmax, false); field("xmin", lm.xmin, false);
+    field("ymax", lm.ymax, false); field("ymin", lm.ymin, false); field("zmax", lm.zmax, false); field("zmin", lm.zmin, true);
+    std::fprintf(fp, "   },\n");
+    key("problem", 3); std::fprintf(fp, "\"%s\",\n", mission.c_str());
+    key("snopt", 3); std::fprintf(fp, "{\n");
+    field("feas_tol", sn.feas_tol, false); field("numbounds", sn.numbounds, false); field("numinp", sn.numinp, false);
+    field("numstates", sn.numstates, false); field("opt_tol", sn.opt_tol, false); field("ts", N, true);
+    std::fprintf(fp, "   },\n");
+    key("trajectory", 3); std::fprintf(fp, "{\n");
+    // JsonCpp orders keys bytewise: upper case first
+    const char *names[12] = {"CL", "T", "Va", "chi", "dCL", "dphi", "gam", "phi", "time", "x", "y", "z"};
+    const int var[12] = {8, 11, 4, 6, 10, 9, 5, 7, -1, 1, 2, 3};     // offset in a node, -1 = time
+    for (int a = 0; a < 12; ++a) {
+        key(names[a], 6); std::fprintf(fp, "[ ");
+        double tm = 0.0;
+        for (int k = 0; k <= N; ++k) {
+            num(var[a] < 0 ? tm : xs[var[a] + 11 * k]);
+            if (k < N) std::fprintf(fp, ", ");
+            tm = tm + xs[0];                 // accumulated like the reference does (:1290)
+        }
+        std::fprintf(fp, a < 11 ? " ],\n" : " ]\n");
+    }
+    std::fprintf(fp, "   }\n}\n");
+    std::fclose(fp);
+}
+
 problemS10::problemS10(const tolfg_config &cfg) : problem(cfg, MISSION_S10) {}
 
 problemG7::problemG7(const tolfg_config &cfg)

@@ -102,6 +102,8 @@ public:
     void evaluate(const double x[], bool needF, double F[], bool needG, double G[]);
 
     void set_wind_table(const double *wind_enu);   // [12][ts+1], ENU, reference member order
+    // ref: problem::writeJSON(filename), src/problem.cpp:1247 -- same keys, for the same consumers
+    void writeJSON(const std::string &filename, const double *xsol, double final_cost) const;
 
     bool debug;                       // ref: problem::debug, include/problem.h:26 (default false here)
 

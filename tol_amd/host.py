@@ -98,6 +98,11 @@ class Problem:
         w = np.ascontiguousarray(wind_enu, dtype=np.float64)
         check(lib().tolfg_set_wind_table(self._h, _d(w)))
 
+    def write_json(self, filename, x, final_cost):
+        """ref: problem::writeJSON -- the `snopt_results.json` the mission glue and MATLAB tools read."""
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        check(lib().tolfg_write_json(self._h, _d(x), float(final_cost), str(filename).encode()))
+
     # ---- the callback, exactly as SNOPT enters it
     def make_current(self):
         lib().tolfg_set_current(self._h)
