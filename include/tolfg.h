@@ -40,8 +40,24 @@ const char *tolfg_last_error(void);
 enum {
     TOLFG_WIND_NONE  = 0,    /* case 0 */
     TOLFG_WIND_SHEAR = 1,    /* case 1, linear boundary layer: the offline fallback (src/problem.cpp:73-78) */
+    TOLFG_WIND_GRID  = 3,    /* case 3, gridded storm field, trilinear interpolation of the v component
+                                and its gradient (src/problem.cpp:544-695); the grid comes from
+                                tolfg_set_wind_grid instead of the reference's MongoDB cache          */
     TOLFG_WIND_TABLE = 99    /* caller-supplied per-node wind; the reference's `default:` arm       */
 };
+
+/* A regular ENU grid of the north wind component v, the only one the reference interpolates
+ * (src/problem.cpp:628-635,682-692).  v[(i*ny + j)*nz + k] is the value at east x0+i*dx, north
+ * y0+j*dy, up z0+k*dz.  The aircraft's grid position is its NED position mapped to ENU plus
+ * (east/north/up)_from_datum (ref: EastFromDatum..., src/problem.cpp:411-413).  Points outside
+ * the grid are evaluated in the edge cell (the reference indexes out of bounds there). */
+typedef struct tolfg_wind_grid {
+    int    nx, ny, nz;        /* >= 2 each */
+    double x0, y0, z0;
+    double dx, dy, dz;        /* 150 m in the reference (include/problem.h:90-92) */
+    double east_from_datum, north_from_datum, up_from_datum;
+    const double *v;          /* host array, nx*ny*nz values */
+} tolfg_wind_grid;
 
 enum { TOLFG_F64 = 0, TOLFG_F32 = 1 };
 
@@ -102,6 +118,8 @@ int tolfg_tolerances(const tolfg_problem *p, double *opt_tol, double *feas_tol);
  * member vectors u v w du_dx du_dy du_dz dv_dx dv_dy dv_dz dw_dx dw_dy dw_dz, ENU convention
  * (ref: include/problem.h:103).  Copied to the device; switches the problem to table wind. */
 int tolfg_set_wind_table(tolfg_problem *p, const double *wind_enu);
+/* Gridded wind (TOLFG_WIND_GRID): copied to the device; switches the problem to wind model 3. */
+int tolfg_set_wind_grid(tolfg_problem *p, const tolfg_wind_grid *grid);
 
 /* Result file of one solved leg, with the keys the reference's writer emits and its consumers read
  * (ref: problem::writeJSON, src/problem.cpp:1247-1365; msl/mission.py:208-226;
@@ -149,6 +167,7 @@ typedef struct tolfg_traj {
     double Vref, href;        /* shear wind of this trajectory (TOLFG_WIND_SHEAR)                  */
     double north_goal, east_goal, radius_goal;
     double xi, yi;            /* start position: G7's course chi_d = atan2(yg-yi, xg-xi)           */
+    double zi;                /* start height (NED, so negative up), used by the device-side set-up */
 } tolfg_traj;
 
 typedef struct tolfg_batch_config {
@@ -171,8 +190,17 @@ int  tolfg_batch_sizes(const tolfg_batch *b, int *n, int *neF, int *neG);
 int  tolfg_batch_pattern(const tolfg_batch *b, int *iGfun, int *jGvar);
 /* Describe (or re-describe) the B trajectories; uploads a small per-trajectory table. */
 int  tolfg_batch_set_trajectories(tolfg_batch *b, int B, const tolfg_traj *trajs);
+/* one gridded wind field for the whole batch (TOLFG_WIND_GRID); copied to the device */
+int  tolfg_batch_set_wind_grid(tolfg_batch *b, const tolfg_wind_grid *grid);
 /* initial guess of trajectory t (host, double) -- the reference's InitialCond with (xi,yi,zi) */
 int  tolfg_batch_x0(const tolfg_batch *b, int t, double zi, double *x);
+/* Set-up on the device for batched warm starts: the initial guess of
+ * trajectories [0,B) written straight into the rows of dX (ref: InitialCond with the trajectory's
+ * (xi,yi,zi)), and the bounds into dXlow/dXupp [B][ldx] and dFlow/dFupp [B][ldf] (ref: setLimits).
+ * Element type = the batch dtype.  Asynchronous on stream. */
+int  tolfg_batch_x0_device(tolfg_batch *b, int B, void *dX, long ldx, void *stream);
+int  tolfg_batch_bounds_device(tolfg_batch *b, int B, void *dXlow, void *dXupp, long ldx,
+                               void *dFlow, void *dFupp, long ldf, void *stream);
 /* bounds of trajectory t (ref: problem::setLimits), any pointer may be NULL */
 int  tolfg_batch_bounds(const tolfg_batch *b, int t, double zi,
                         double *xlow, double *xupp, double *Flow, double *Fupp);

@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 DATA = os.path.join(os.path.dirname(HERE), "tol_amd", "data")
 
 S10, G7 = 0, 1
-WIND_NONE, WIND_SHEAR, WIND_TABLE = 0, 1, 99
+WIND_NONE, WIND_SHEAR, WIND_GRID, WIND_TABLE = 0, 1, 3, 99
 MISSION_ID = {"S10": S10, "G7": G7}
 
 _dp = C.POINTER(C.c_double)
@@ -29,7 +29,12 @@ class OrcProblem(C.Structure):
                 ("xg", C.c_double), ("yg", C.c_double), ("rg", C.c_double),
                 ("chi_d", C.c_double),
                 ("windmodel", C.c_int), ("Vref", C.c_double), ("href", C.c_double),
-                ("wind", _dp)]
+                ("wind", _dp),
+                ("gnx", C.c_int), ("gny", C.c_int), ("gnz", C.c_int),
+                ("gx0", C.c_double), ("gy0", C.c_double), ("gz0", C.c_double),
+                ("gdx", C.c_double), ("gdy", C.c_double), ("gdz", C.c_double),
+                ("gE", C.c_double), ("gN", C.c_double), ("gU", C.c_double),
+                ("gv", _dp)]
 
 
 def build(opt="O2"):
@@ -107,7 +112,7 @@ class Problem:
 
     def __init__(self, mission, aircraft="tempest", N=None, east_goal=400.0, north_goal=0.0,
                  radius_goal=100.0, start=(0.0, 0.0, 0.0), windmodel=WIND_SHEAR, Vref=2.4, href=10.0,
-                 wind_table=None, data_root=DATA, gains=None):
+                 wind_table=None, data_root=DATA, gains=None, wind_grid=None):
         self.mission = mission
         self.mid = MISSION_ID[mission]
         self.aircraft = aircraft
@@ -146,6 +151,15 @@ class Problem:
             assert self._wind.shape == (12, self.N + 1)
             p.wind = _d(self._wind)
             p.windmodel = WIND_TABLE
+        if wind_grid is not None:
+            # dict: v[nx][ny][nz], origin (x0,y0,z0), spacing (dx,dy,dz), datum (E,N,U)  -- wind model 3
+            self._gv = np.ascontiguousarray(wind_grid["v"], dtype=np.float64)
+            p.gnx, p.gny, p.gnz = self._gv.shape
+            p.gx0, p.gy0, p.gz0 = wind_grid["origin"]
+            p.gdx, p.gdy, p.gdz = wind_grid["spacing"]
+            p.gE, p.gN, p.gU = wind_grid["datum"]
+            p.gv = _d(self._gv)
+            p.windmodel = WIND_GRID
         self.c = p
 
     # ---- setup pieces

@@ -206,6 +206,38 @@ static void wind_at(const orc_problem *p, const double *x, int k, ned_wind *w)
         enu[8] = -p->Vref / p->href;
     } else if (p->windmodel == ORC_WIND_TABLE) {
         for (int f = 0; f < 12; f++) enu[f] = p->wind[(size_t)f * (p->N + 1) + k];
+    } else if (p->windmodel == ORC_WIND_GRID) {
+        /* src/problem.cpp:551-692.  ENU <- NED, then the cell whose lower corner is the first grid
+         * coordinate within one spacing below the point (the reference's three search loops), then
+         * the eight-node trilinear shape functions and their derivatives; only v is interpolated.
+         * Points outside the grid use the edge cell (the reference indexes out of bounds there). */
+        const double xs = x[k * ORC_NI + 2] + p->gE, ys = x[k * ORC_NI + 1] + p->gN, zs = -x[k * ORC_NI + 3] + p->gU;
+        int xi, yi, zi;
+        for (xi = 0; xi < p->gnx - 2; xi++) if (xs - (p->gx0 + xi * p->gdx) < p->gdx) break;
+        for (yi = 0; yi < p->gny - 2; yi++) if (ys - (p->gy0 + yi * p->gdy) < p->gdy) break;
+        for (zi = 0; zi < p->gnz - 2; zi++) if (zs - (p->gz0 + zi * p->gdz) < p->gdz) break;
+        double vc[8];
+        for (int c = 0; c < 8; c++) {
+            const int i = xi + (c & 1), j = yi + ((c >> 1) & 1), l = zi + (c >> 2);
+            vc[c] = p->gv[((size_t)i * p->gny + j) * p->gnz + l];
+        }
+        const double dx = p->gdx, dy = p->gdy, dz = p->gdz;
+        const double xrel = xs - (p->gx0 + xi * dx), yrel = ys - (p->gy0 + yi * dy), zrel = zs - (p->gz0 + zi * dz);
+        const double ze = xrel / dx, et = yrel / dy, mu = zrel / dz;
+        const double Nf[8] = {(1 - ze) * (1 - et) * (1 - mu), ze * (1 - et) * (1 - mu), (1 - ze) * et * (1 - mu), ze * et * (1 - mu),
+                              (1 - ze) * (1 - et) * mu,       ze * (1 - et) * mu,       (1 - ze) * et * mu,       ze * et * mu};
+        const double NX[8] = {-(1 - et) * (1 - mu) / dx, (1 - et) * (1 - mu) / dx, -et * (1 - mu) / dx, et * (1 - mu) / dx,
+                              -(1 - et) * mu / dx,       (1 - et) * mu / dx,       -et * mu / dx,       et * mu / dx};
+        const double NY[8] = {-(1 - ze) * (1 - mu) / dy, -ze * (1 - mu) / dy, (1 - ze) * (1 - mu) / dy, ze * (1 - mu) / dy,
+                              -(1 - ze) * mu / dy,       -ze * mu / dy,       (1 - ze) * mu / dy,       ze * mu / dy};
+        const double NZ[8] = {-(1 - ze) * (1 - et) / dz, -ze * (1 - et) / dz, -(1 - ze) * et / dz, -ze * et / dz,
+                              (1 - ze) * (1 - et) / dz,  ze * (1 - et) / dz,  (1 - ze) * et / dz,  ze * et / dz};
+        for (int c = 0; c < 8; c++) {
+            enu[1] += Nf[c] * vc[c];
+            enu[6] += NX[c] * vc[c];
+            enu[7] += NY[c] * vc[c];
+            enu[8] += NZ[c] * vc[c];
+        }
     }
     /* NED <- ENU, src/problem.cpp:970-981 (== :1061-1072) */
     const double u = enu[0], v = enu[1], ww = enu[2];

@@ -28,7 +28,7 @@ extern "C" {
 #endif
 
 enum { ORC_S10 = 0, ORC_G7 = 1 };
-enum { ORC_WIND_NONE = 0, ORC_WIND_SHEAR = 1, ORC_WIND_TABLE = 99 };
+enum { ORC_WIND_NONE = 0, ORC_WIND_SHEAR = 1, ORC_WIND_GRID = 3, ORC_WIND_TABLE = 99 };
 
 /* numinp / numstates: problems/{S10,G7}/snopt.param:3-4 */
 enum { ORC_NI = 11, ORC_NS = 8 };
@@ -52,6 +52,14 @@ typedef struct {
      * (include/problem.h:103): wind[f*(N+1)+k], f = 0..11 in the order
      * u v w du_dx du_dy du_dz dv_dx dv_dy dv_dz dw_dx dw_dy dw_dz */
     const double *wind;
+    /* wind model 3, the gridded storm field (src/problem.cpp:544-695): a regular ENU grid of the
+     * v (north) component, the only one the reference interpolates; gv[(i*gny + j)*gnz + k] is the
+     * value at east gx0+i*gdx, north gy0+j*gdy, up gz0+k*gdz; aircraft position in the grid frame =
+     * NED position mapped to ENU plus (gE, gN, gU) (EastFromDatum..., src/problem.cpp:411-413).
+     * PARITY UNPINNED: no wind data and no reference output exist for this model. */
+    int    gnx, gny, gnz;
+    double gx0, gy0, gz0, gdx, gdy, gdz, gE, gN, gU;
+    const double *gv;
 } orc_problem;
 
 /* .param reader: src/parameters.cpp:14-34.  Returns the number of values parsed (<= maxn) or -1

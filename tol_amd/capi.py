@@ -5,7 +5,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 OK, ERR_ARG, ERR_PARAM, ERR_HIP, ERR_NOCURRENT = 0, -1, -2, -3, -4
-WIND_NONE, WIND_SHEAR, WIND_TABLE = 0, 1, 99
+WIND_NONE, WIND_SHEAR, WIND_GRID, WIND_TABLE = 0, 1, 3, 99
 F64, F32 = 0, 1
 PATTERN_REFERENCE, PATTERN_COMPACT = 0, 1
 PATTERNS = {"reference": 0, "compact": 1}
@@ -36,7 +36,15 @@ class Traj(C.Structure):
     _fields_ = [("aircraft", C.c_int), ("reserved", C.c_int),
                 ("Vref", C.c_double), ("href", C.c_double),
                 ("north_goal", C.c_double), ("east_goal", C.c_double), ("radius_goal", C.c_double),
-                ("xi", C.c_double), ("yi", C.c_double)]
+                ("xi", C.c_double), ("yi", C.c_double), ("zi", C.c_double)]
+
+
+class WindGrid(C.Structure):
+    _fields_ = [("nx", C.c_int), ("ny", C.c_int), ("nz", C.c_int),
+                ("x0", C.c_double), ("y0", C.c_double), ("z0", C.c_double),
+                ("dx", C.c_double), ("dy", C.c_double), ("dz", C.c_double),
+                ("east_from_datum", C.c_double), ("north_from_datum", C.c_double), ("up_from_datum", C.c_double),
+                ("v", _dp)]
 
 
 class BatchConfig(C.Structure):
@@ -64,6 +72,8 @@ SYMBOLS = {
     "tolfg_bounds": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _dp]),
     "tolfg_tolerances": (C.c_int, [C.c_void_p, _dp, _dp]),
     "tolfg_set_wind_table": (C.c_int, [C.c_void_p, _dp]),
+    "tolfg_set_wind_grid": (C.c_int, [C.c_void_p, C.POINTER(WindGrid)]),
+    "tolfg_batch_set_wind_grid": (C.c_int, [C.c_void_p, C.POINTER(WindGrid)]),
     "tolfg_write_json": (C.c_int, [C.c_void_p, _dp, C.c_double, C.c_char_p]),
     "tolfg_set_current": (None, [C.c_void_p]),
     "tolfg_get_current": (C.c_void_p, []),
@@ -78,6 +88,9 @@ SYMBOLS = {
     "tolfg_batch_pattern": (C.c_int, [C.c_void_p, _ip, _ip]),
     "tolfg_batch_set_trajectories": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Traj)]),
     "tolfg_batch_x0": (C.c_int, [C.c_void_p, C.c_int, C.c_double, _dp]),
+    "tolfg_batch_x0_device": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_long, C.c_void_p]),
+    "tolfg_batch_bounds_device": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_long, C.c_void_p, C.c_void_p,
+                                            C.c_long, C.c_void_p]),
     "tolfg_batch_bounds": (C.c_int, [C.c_void_p, C.c_int, C.c_double, _dp, _dp, _dp, _dp]),
     "tolfg_batch_eval": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_long, C.c_void_p, C.c_long,
                                    C.c_void_p, C.c_long, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),

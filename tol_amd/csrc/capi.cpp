@@ -172,6 +172,12 @@ int tolfg_set_wind_table(tolfg_problem *h, const double *wind_enu)
     return guarded([&] { h->p->set_wind_table(wind_enu); });
 }
 
+int tolfg_set_wind_grid(tolfg_problem *h, const tolfg_wind_grid *grid)
+{
+    if (!h || !grid) return fail(TOLFG_ERR_ARG, "null argument");
+    return guarded([&] { h->p->set_wind_grid(*grid); });
+}
+
 int tolfg_write_json(const tolfg_problem *h, const double *x, double final_cost, const char *filename)
 {
     if (!h || !x || !filename) return fail(TOLFG_ERR_ARG, "null argument");
@@ -283,6 +289,12 @@ int tolfg_batch_set_trajectories(tolfg_batch *h, int B, const tolfg_traj *trajs)
     return guarded([&] { h->b->set_trajectories(B, trajs); });
 }
 
+int tolfg_batch_set_wind_grid(tolfg_batch *h, const tolfg_wind_grid *grid)
+{
+    if (!h || !grid) return fail(TOLFG_ERR_ARG, "null argument");
+    return guarded([&] { h->b->set_wind_grid(*grid); });
+}
+
 int tolfg_batch_x0(const tolfg_batch *h, int t, double zi, double *x)
 {
     if (!h || !x) return fail(TOLFG_ERR_ARG, "null argument");
@@ -290,6 +302,19 @@ int tolfg_batch_x0(const tolfg_batch *h, int t, double zi, double *x)
         const tolfg_traj &tr = h->b->trajectory(t);
         initial_guess(h->b->sizes(), h->b->airframe(tr.aircraft), Start{tr.xi, tr.yi, zi}, h->b->chi_d(t), x);
     });
+}
+
+int tolfg_batch_x0_device(tolfg_batch *h, int B, void *dX, long ldx, void *stream)
+{
+    if (!h) return fail(TOLFG_ERR_ARG, "null batch");
+    return guarded([&] { h->b->x0_device(B, dX, ldx, static_cast<hipStream_t>(stream)); });
+}
+
+int tolfg_batch_bounds_device(tolfg_batch *h, int B, void *dXlow, void *dXupp, long ldx, void *dFlow, void *dFupp,
+                              long ldf, void *stream)
+{
+    if (!h) return fail(TOLFG_ERR_ARG, "null batch");
+    return guarded([&] { h->b->bounds_device(B, dXlow, dXupp, ldx, dFlow, dFupp, ldf, static_cast<hipStream_t>(stream)); });
 }
 
 int tolfg_batch_bounds(const tolfg_batch *h, int t, double zi, double *xlow, double *xupp, double *Flow,

@@ -7,7 +7,7 @@
 namespace tolfg {
 
 enum { MISSION_S10 = 0, MISSION_G7 = 1 };
-enum { WIND_NONE = 0, WIND_SHEAR = 1, WIND_TABLE = 2 };   // kernel-side enumeration
+enum { WIND_NONE = 0, WIND_SHEAR = 1, WIND_TABLE = 2, WIND_GRID = 3 };   // kernel-side enumeration
 enum { MAX_AIRCRAFT = 8 };
 enum { PATTERN_REFERENCE = 0, PATTERN_COMPACT = 1 };   // slab_table.h
 
@@ -19,6 +19,13 @@ struct AcCoef {
     double qk;         // rho*SS/(2*mm)        so that q = qk*Va^2
     double Cd0;
     double kind;       // 1/(AR*pi*ee)         induced-drag factor
+    double mm, SS, AR, ee;   // as read, for the initial-guess kernel (same operations as the host code)
+};
+
+// Bounds of the nodes k >= 1 and the step (ref: problem::setLimits, src/problem.cpp:272-285,267);
+// lo/up in node-variable order x y z Va gam chi phi CL dphi dCL T.
+struct AcBounds {
+    double lo[11], up[11];
 };
 
 // Per-trajectory constants, one record per trajectory in device memory.
@@ -28,6 +35,18 @@ struct TrajDev {
     double cchi, schi; // cos/sin of G7's chi_d (src/problemG7.cpp:524)
     int    ac;         // index into FgArgs::ac
     int    pad;
+    double xi, yi, zi; // start position (src/problem.cpp:83-85), for the initial-guess and bounds kernels
+    double chi_d;
+};
+
+// Wind model 3, the gridded storm field (ref: problem::modelWind case 3, src/problem.cpp:544-695):
+// regular ENU grid of the v (north) component -- the only one the reference interpolates.
+struct GridDev {
+    const void *v;             // [nx][ny][nz] elements of the batch dtype, device
+    int    nx, ny, nz, pad;
+    double x0, y0, z0;         // ENU coordinates of grid point (0,0,0)
+    double dx, dy, dz;         // spacing (150 m in the reference, include/problem.h:90-92)
+    double e0, n0, u0;         // EastFromDatum, NorthFromDatum, UpFromDatum (src/problem.cpp:411-413)
 };
 
 struct FgArgs {
@@ -35,6 +54,7 @@ struct FgArgs {
     void          *F;      long ldf;
     void          *G;      long ldg;
     const void    *wind;   // [B][12][N+1] (ENU, reference member order) or nullptr
+    GridDev        grid;   // WIND_GRID only
     const TrajDev *traj;   // [B]
     int  B, N, c0;
     int  tiles, nt;        // tiles per trajectory and nodes per tile, from plan_tiles()
@@ -63,6 +83,19 @@ hipError_t launch_fg(const FgArgs &a, int mission, int wind, int dtype, int vec,
 
 // dObj[t] = F[t*ldf]
 hipError_t launch_objectives(const void *F, long ldf, void *obj, int B, int dtype, hipStream_t s);
+
+// Initial guess of B trajectories straight into device rows (ref: problemS10::InitialCond /
+// problemG7::InitialCond); bounds likewise (ref: problem::setLimits).  One-time set-up kernels.
+hipError_t launch_x0(const FgArgs &a, int mission, int dtype, hipStream_t s);
+struct BoundsArgs {
+    void *xlow, *xupp; long ldx;
+    void *Flow, *Fupp; long ldf;
+    const TrajDev *traj;
+    int B, N, nb, mission;
+    double dtmin, dtmax;
+    AcBounds ac[MAX_AIRCRAFT];
+};
+hipError_t launch_bounds(const BoundsArgs &a, int dtype, hipStream_t s);
 
 // LDS bytes per workgroup of the fg kernel (for DESIGN.md / occupancy reporting)
 int fg_lds_bytes(int dtype);

@@ -113,7 +113,7 @@ __device__ __forceinline__ T dotw(T e0, T e1, T e2, const T (&V)[3])
 {
     if constexpr (WIND == WIND_NONE) return T(0);
     else if constexpr (WIND == WIND_SHEAR) return e2 * V[2];
-    else return e0 * V[0] + e1 * V[1] + e2 * V[2];
+    else return e0 * V[0] + e1 * V[1] + e2 * V[2];     // WIND_TABLE, WIND_GRID
 }
 
 // Per-node evaluation in two steps so that the defects can leave (and their registers die) before
@@ -125,8 +125,32 @@ template <typename T, int WIND> struct NodeCtx {
     T A[3], B[3], C[3], H[3];
     T v0, v1, v2, vA, vB, vC, vH, iVa, icg, qV, q, CD, N5, N6, inv_m, kind, dphi, dCL;
 
+    // Trilinear interpolation of the gridded v component and its gradient at one ENU point
+    // (ref: src/problem.cpp:551-692).  Returns v, d v / d(east, north, up).
+    __device__ __forceinline__ static void grid_wind(const GridDev &gr, T pn, T pe, T pd, T &v, T &dve, T &dvn, T &dvu)
+    {
+        const T xs = pe + T(gr.e0), ys = pn + T(gr.n0), zs = -pd + T(gr.u0);
+        const T dx = T(gr.dx), dy = T(gr.dy), dz = T(gr.dz);
+        // lower corner: the first grid coordinate within one spacing below the point, edge cell outside
+        const int xi = min(max((int)floor((xs - T(gr.x0)) / dx), 0), gr.nx - 2);
+        const int yi = min(max((int)floor((ys - T(gr.y0)) / dy), 0), gr.ny - 2);
+        const int zi = min(max((int)floor((zs - T(gr.z0)) / dz), 0), gr.nz - 2);
+        const T *g = static_cast<const T *>(gr.v) + ((long)xi * gr.ny + yi) * gr.nz + zi;
+        const long sx_ = (long)gr.ny * gr.nz, sy_ = gr.nz;
+        const T v0 = g[0], v1 = g[sx_], v2 = g[sy_], v3 = g[sx_ + sy_];
+        const T v4 = g[1], v5 = g[sx_ + 1], v6 = g[sy_ + 1], v7 = g[sx_ + sy_ + 1];
+        const T ze = (xs - (T(gr.x0) + T(xi) * dx)) / dx, et = (ys - (T(gr.y0) + T(yi) * dy)) / dy;
+        const T mu = (zs - (T(gr.z0) + T(zi) * dz)) / dz;
+        const T a = T(1) - ze, b = T(1) - et, c = T(1) - mu;
+        v = a * b * c * v0 + ze * b * c * v1 + a * et * c * v2 + ze * et * c * v3 +
+            a * b * mu * v4 + ze * b * mu * v5 + a * et * mu * v6 + ze * et * mu * v7;
+        dve = ((v1 - v0) * b * c + (v3 - v2) * et * c + (v5 - v4) * b * mu + (v7 - v6) * et * mu) / dx;
+        dvn = ((v2 - v0) * a * c + (v3 - v1) * ze * c + (v6 - v4) * a * mu + (v7 - v5) * ze * mu) / dy;
+        dvu = ((v4 - v0) * a * b + (v5 - v1) * ze * b + (v6 - v2) * a * et + (v7 - v3) * ze * et) / dz;
+    }
+
     __device__ __forceinline__ void rates(const T (&s)[NI], T dt_, T shear, const T (&we)[12], T inv_m_, T qk, T Cd0,
-                                          T kind_, T (&f)[8])
+                                          T kind_, T (&f)[8], const GridDev &gr)
     {
         Va = s[3]; CL = s[7]; dt = dt_; inv_m = inv_m_; kind = kind_; dphi = s[8]; dCL = s[9];
         const T Th = s[10];
@@ -153,6 +177,16 @@ template <typename T, int WIND> struct NodeCtx {
             B[0] = eg0 * J00 + eg1 * J10 + eg2 * J20; B[1] = eg0 * J01 + eg1 * J11 + eg2 * J21; B[2] = eg0 * J02 + eg1 * J12 + eg2 * J22;
             C[0] = -sx * J00 + cx * J10; C[1] = -sx * J01 + cx * J11; C[2] = -sx * J02 + cx * J12;
             H[0] = cx * J00 + sx * J10;  H[1] = cx * J01 + sx * J11;  H[2] = cx * J02 + sx * J12;
+        } else if constexpr (WIND == WIND_GRID) {
+            // only Wx (= ENU v) is non-zero: dWx/dx_NED = dv/dnorth, dWx/dy_NED = dv/deast, dWx/dz_NED = -dv/dup
+            T v, dve, dvn, dvu;
+            grid_wind(gr, s[0], s[1], s[2], v, dve, dvn, dvu);
+            W[0] = v;
+            const T J00 = dvn, J01 = dve, J02 = -dvu;
+            A[0] = ea0 * J00; A[1] = ea0 * J01; A[2] = ea0 * J02;
+            B[0] = eg0 * J00; B[1] = eg0 * J01; B[2] = eg0 * J02;
+            C[0] = -sx * J00; C[1] = -sx * J01; C[2] = -sx * J02;
+            H[0] = cx * J00;  H[1] = cx * J01;  H[2] = cx * J02;
         }
         v0 = W[0] + Va * ea0; v1 = W[1] + Va * ea1; v2 = W[2] + Va * ea2;
         vA = dotw<WIND>(v0, v1, v2, A); vB = dotw<WIND>(v0, v1, v2, B);
@@ -372,7 +406,7 @@ __global__ __launch_bounds__(TILE, TOLFG_MIN_WAVES_PER_SIMD) void fg_kernel(cons
         for (int r = 0; r < 8; r++) f[r] = s[r];
     } else
 #endif
-    nc.rates(s, dt, T(tr.shear), we, T(ac.inv_m), T(ac.qk), T(ac.Cd0), T(ac.kind), f);
+    nc.rates(s, dt, T(tr.shear), we, T(ac.inv_m), T(ac.qk), T(ac.Cd0), T(ac.kind), f, a.grid);
 
     // ---- defects leave first (src/problem.cpp:1012-1019); sn dies here
     if (a.needF && act && !(TOLFG_VARIANT(a) & 512)) {
@@ -594,6 +628,7 @@ hipError_t launch_wind(const FgArgs &a, int wind, int vec, dim3 grid, hipStream_
     case WIND_NONE:  return launch_vec<T, MISSION, WIND_NONE, PAT>(a, vec, grid, s, t0, t1);
     case WIND_SHEAR: return launch_vec<T, MISSION, WIND_SHEAR, PAT>(a, vec, grid, s, t0, t1);
     case WIND_TABLE: return launch_vec<T, MISSION, WIND_TABLE, PAT>(a, vec, grid, s, t0, t1);
+    case WIND_GRID:  return launch_vec<T, MISSION, WIND_GRID, PAT>(a, vec, grid, s, t0, t1);
     }
     return hipErrorInvalidValue;
 }
@@ -604,6 +639,126 @@ hipError_t launch_mission(const FgArgs &a, int mission, int wind, int vec, dim3 
 {
     return mission == MISSION_S10 ? launch_wind<T, MISSION_S10, PAT>(a, wind, vec, grid, s, t0, t1)
                                   : launch_wind<T, MISSION_G7, PAT>(a, wind, vec, grid, s, t0, t1);
+}
+
+
+// ---- set-up kernels: initial guess and bounds generated on the device.
+// One thread per trajectory walks its nodes in order, exactly like the host code in setup.cpp does
+// (the course unwrap and the control rates depend on the previous node).
+__device__ __forceinline__ double atan2_t(double y, double x) { return atan2(y, x); }
+
+template <typename T, int MISSION>
+__global__ void x0_kernel(const FgArgs a)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= a.B) return;
+    constexpr double kRho = 1.2682, kPi = 3.14159265358979323846;
+    const bool loiter = MISSION == MISSION_S10;
+    const int N = a.N;
+    const TrajDev tr = a.traj[b];
+    const AcCoef ac = a.ac[tr.ac];
+    T *x = static_cast<T *>(const_cast<void *>(a.X)) + (long)b * a.ldx;
+    const double tfinal = loiter ? 20.0 : 10.0;
+    const double ax = loiter ? 100.0 : 40.0, ay = loiter ? 100.0 : 0.0, az = 0.0;
+    const double dt = tfinal / N;
+    const double w = 2.0 * kPi / tfinal;
+    const double cd = cos(tr.chi_d), sd = sin(tr.chi_d);
+    double t = 0.0, chi_prev = 0.0, phi_prev = 0.0, CL_prev = 0.0, dphi_last = 0.0, dCL_last = 0.0;
+    for (int k = 0; k <= N; ++k, t = t + dt) {
+        const double s = sin(w * t), c = cos(w * t);
+        double p[3], v[3], acc[3];
+        if (loiter) {
+            p[0] = ax * s - ax + tr.xi;     p[1] = -ay * c + tr.yi;        p[2] = az * c - az + tr.zi;
+            v[0] = w * ax * c;              v[1] = w * ay * s;             v[2] = -w * az * s;
+            acc[0] = -w * w * ax * s;       acc[1] = w * w * ay * c;       acc[2] = -w * w * az * c;
+        } else {
+            const double px = ax / tfinal * t + tr.xi, py = -ay * c + ay + tr.yi;
+            p[0] = cd * px - sd * py;
+            p[1] = sd * px + cd * py;
+            p[2] = az * c - az + tr.zi;
+            v[0] = ax / tfinal;             v[1] = ay * w * s;             v[2] = -az * w * s;
+            acc[0] = 0.0;                   acc[1] = ay * w * w * c;       acc[2] = -az * w * w * c;
+        }
+        const double Va = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+        double chi = atan2_t(v[1], v[0]) + (loiter ? 0.0 : tr.chi_d);
+        const double gam = atan2_t(-v[2], sqrt(v[0] * v[0] + v[1] * v[1]));
+        if (k > 0) {
+            double jump = chi - chi_prev;
+            while (jump < -kPi || jump > kPi) {
+                if (jump < -kPi) chi = chi + 2.0 * kPi * ceil((-kPi - jump) / (2.0 * kPi));
+                if (jump > kPi) chi = chi + 2.0 * kPi * floor((kPi - jump) / (2.0 * kPi));
+                jump = chi - chi_prev;
+            }
+        }
+        const double u[3] = {v[0] / Va, v[1] / Va, v[2] / Va};
+        const double sf[3] = {acc[0], acc[1], acc[2] - kGrav};
+        const double n0 = -sf[0] * (u[0] * u[0] - 1.0) - u[0] * u[1] * sf[1] - u[0] * u[2] * sf[2];
+        const double n1 = -sf[1] * (u[1] * u[1] - 1.0) - u[0] * u[1] * sf[0] - u[1] * u[2] * sf[2];
+        const double n2 = -sf[2] * (u[2] * u[2] - 1.0) - u[0] * u[2] * sf[0] - u[1] * u[2] * sf[1];
+        const double nmag = sqrt(n0 * n0 + n1 * n1 + n2 * n2);
+        const double l0 = -n0 / nmag, l1 = -n1 / nmag, l2 = -n2 / nmag;
+        const double phi = atan2_t(l0 * u[1] - l1 * u[0], l2);
+        const double CL = 2.0 * (ac.mm * nmag) / (kRho * Va * Va * ac.SS);
+        const double drag = 0.5 * kRho * Va * Va * ac.SS * (ac.Cd0 + CL * CL / (kPi * ac.AR * ac.ee));
+        const double thrust = ac.mm * (u[0] * sf[0] + u[1] * sf[1] + u[2] * sf[2]) + drag;
+        T *nd = x + 11 * k + 1;
+        dphi_last = k ? (phi - phi_prev) / dt : 0.0;
+        dCL_last = k ? (CL - CL_prev) / dt : 0.0;
+        nd[0] = T(p[0]); nd[1] = T(p[1]); nd[2] = T(p[2]);
+        nd[3] = T(Va); nd[4] = T(gam); nd[5] = T(chi); nd[6] = T(phi); nd[7] = T(CL);
+        nd[8] = T(dphi_last); nd[9] = T(dCL_last); nd[10] = T(thrust);
+        chi_prev = chi; phi_prev = phi; CL_prev = CL;
+    }
+    x[0] = T(dt);
+    if (loiter) {   // src/problemS10.cpp:210-211
+        x[9] = T(dphi_last);
+        x[10] = T(dCL_last);
+    }
+}
+
+// bounds: one thread per element of the x row / F row
+template <typename T>
+__global__ void bounds_kernel(const BoundsArgs a)
+{
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = 11 * (a.N + 1) + 1, neF = 8 * a.N + 1 + a.nb;
+    const TrajDev tr = a.traj[b];
+    if (i < n) {
+        double lo, up;
+        if (i == 0) { lo = a.dtmin; up = a.dtmax; }
+        else {
+            const int k = (i - 1) / 11, m = (i - 1) % 11;
+            if (k > 0) { lo = a.ac[tr.ac].lo[m]; up = a.ac[tr.ac].up[m]; }
+            else {
+                // node 0 is pinned to the start with the constants of src/problem.cpp:80-134
+                constexpr double kPi = 3.14159265358979323846;
+                const bool loiter = a.mission == MISSION_S10;
+                switch (m) {
+                case 0: lo = up = tr.xi; break;
+                case 1: lo = up = tr.yi; break;
+                case 2: lo = up = tr.zi; break;
+                case 3: lo = 4.0; up = 50.0; break;
+                case 4: lo = 0.0; up = 0.0; break;
+                case 5: up = loiter ? 1.7453292519943296e+18 : 1e20 * kPi / 180.0; lo = -up; break;
+                case 6: up = loiter ? 1.5707963267948966 : 90.0 * kPi / 180.0; lo = -up; break;
+                case 7: lo = -0.5; up = 3.0; break;
+                case 8: lo = -3.4906585039886591; up = 3.4906585039886591; break;
+                case 9: lo = -200.0; up = 200.0; break;
+                default: lo = 0.0; up = 1e20; break;
+                }
+            }
+        }
+        static_cast<T *>(a.xlow)[(long)b * a.ldx + i] = T(lo);
+        static_cast<T *>(a.xupp)[(long)b * a.ldx + i] = T(up);
+    }
+    if (i < neF) {
+        double lo = 0.0, up = 0.0;
+        if (i == 0) { lo = -1e20; up = 1e20; }
+        else if (a.mission == MISSION_G7 && i == neF - 1) lo = -1e20;     // dist <= dmax
+        static_cast<T *>(a.Flow)[(long)b * a.ldf + i] = T(lo);
+        static_cast<T *>(a.Fupp)[(long)b * a.ldf + i] = T(up);
+    }
 }
 
 }  // namespace
@@ -649,6 +804,30 @@ hipError_t launch_objectives(const void *F, long ldf, void *obj, int B, int dtyp
     else
         hipLaunchKernelGGL(objectives_kernel<float>, grid, block, 0, s, static_cast<const float *>(F), ldf,
                            static_cast<float *>(obj), B);
+    return hipGetLastError();
+}
+
+hipError_t launch_x0(const FgArgs &a, int mission, int dtype, hipStream_t s)
+{
+    if (a.B <= 0) return hipSuccess;
+    const dim3 grid((a.B + 63) / 64), block(64);
+    if (dtype == 0) {
+        if (mission == MISSION_S10) hipLaunchKernelGGL((x0_kernel<double, MISSION_S10>), grid, block, 0, s, a);
+        else                        hipLaunchKernelGGL((x0_kernel<double, MISSION_G7>), grid, block, 0, s, a);
+    } else {
+        if (mission == MISSION_S10) hipLaunchKernelGGL((x0_kernel<float, MISSION_S10>), grid, block, 0, s, a);
+        else                        hipLaunchKernelGGL((x0_kernel<float, MISSION_G7>), grid, block, 0, s, a);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_bounds(const BoundsArgs &a, int dtype, hipStream_t s)
+{
+    if (a.B <= 0) return hipSuccess;
+    const int n = 11 * (a.N + 1) + 1;
+    const dim3 grid((n + 255) / 256, a.B), block(256);
+    if (dtype == 0) hipLaunchKernelGGL(bounds_kernel<double>, grid, block, 0, s, a);
+    else            hipLaunchKernelGGL(bounds_kernel<float>, grid, block, 0, s, a);
     return hipGetLastError();
 }
 

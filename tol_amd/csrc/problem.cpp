@@ -30,6 +30,7 @@ int kernel_wind(int windmodel)
     case TOLFG_WIND_NONE:  return WIND_NONE;
     case TOLFG_WIND_SHEAR: return WIND_SHEAR;
     case TOLFG_WIND_TABLE: return WIND_TABLE;
+    case TOLFG_WIND_GRID:  return WIND_GRID;
     }
     throw std::invalid_argument("unknown wind model");
 }
@@ -89,6 +90,7 @@ batch::batch(const std::string &mission, const std::string &root, const std::vec
         args_.ac[i].qk = kRho * a.SS / (2.0 * a.mm);
         args_.ac[i].Cd0 = a.Cd0;
         args_.ac[i].kind = 1.0 / (a.AR * M_PI * a.ee);
+        args_.ac[i].mm = a.mm; args_.ac[i].SS = a.SS; args_.ac[i].AR = a.AR; args_.ac[i].ee = a.ee;
     }
 }
 
@@ -96,7 +98,30 @@ batch::~batch()
 {
     if (d_traj_) (void)hipFree(d_traj_);
     if (d_partial_) (void)hipFree(d_partial_);
+    if (d_grid_) (void)hipFree(d_grid_);
     for (hipEvent_t e : ev_) if (e) (void)hipEventDestroy(e);
+}
+
+void batch::set_wind_grid(const tolfg_wind_grid &g)
+{
+    if (!g.v || g.nx < 2 || g.ny < 2 || g.nz < 2 || !(g.dx > 0) || !(g.dy > 0) || !(g.dz > 0))
+        throw std::invalid_argument("wind grid: need >= 2 points per axis, positive spacing and values");
+    const size_t cnt = (size_t)g.nx * g.ny * g.nz;
+    check(hipSetDevice(device_), "hipSetDevice");
+    if (d_grid_) check(hipFree(d_grid_), "hipFree");
+    d_grid_ = nullptr;
+    check(hipMalloc(&d_grid_, elem_size() * cnt), "hipMalloc(grid)");
+    if (dtype_ == TOLFG_F64) {
+        check(hipMemcpy(d_grid_, g.v, sizeof(double) * cnt, hipMemcpyHostToDevice), "hipMemcpy(grid)");
+    } else {
+        std::vector<float> tmp(g.v, g.v + cnt);
+        check(hipMemcpy(d_grid_, tmp.data(), sizeof(float) * cnt, hipMemcpyHostToDevice), "hipMemcpy(grid)");
+    }
+    GridDev &d = args_.grid;
+    d.v = d_grid_; d.nx = g.nx; d.ny = g.ny; d.nz = g.nz; d.pad = 0;
+    d.x0 = g.x0; d.y0 = g.y0; d.z0 = g.z0; d.dx = g.dx; d.dy = g.dy; d.dz = g.dz;
+    d.e0 = g.east_from_datum; d.n0 = g.north_from_datum; d.u0 = g.up_from_datum;
+    windmodel_ = TOLFG_WIND_GRID;
 }
 
 double batch::chi_d(int t) const
@@ -118,6 +143,7 @@ void batch::set_trajectories(int B, const tolfg_traj *trajs)
         const double cd = std::atan2(tr.east_goal - tr.yi, tr.north_goal - tr.xi);
         d.cchi = std::cos(cd); d.schi = std::sin(cd);
         d.ac = tr.aircraft; d.pad = 0;
+        d.xi = tr.xi; d.yi = tr.yi; d.zi = tr.zi; d.chi_d = cd;
     }
     host_traj_.assign(trajs, trajs + B);
     dev_traj_.swap(dev);
@@ -147,6 +173,7 @@ void batch::eval(int B, const void *dX, long ldx, void *dF, long ldf, void *dG, 
     if (ldx < sz_.n || (needF && ldf < sz_.neF) || (needG && ldg < sz_.neG))
         throw std::invalid_argument("eval: leading dimension smaller than the row");
     if (windmodel_ == TOLFG_WIND_TABLE && !dWind) throw std::invalid_argument("eval: table wind needs dWind");
+    if (windmodel_ == TOLFG_WIND_GRID && !d_grid_) throw std::invalid_argument("eval: grid wind needs tolfg_*_set_wind_grid");
     if (!uploaded_) upload();
     const long W = (long)B * args_.tiles;
     if (W > partial_cap_) {        // objective partials, 2 doubles per tile
@@ -202,6 +229,33 @@ int batch::kernel_time(double *avg_ms, double *min_ms)
     if (min_ms) *min_ms = pairs ? mn : 0.0;
     ev_used_ = 0;
     return pairs;
+}
+
+void batch::x0_device(int B, void *dX, long ldx, hipStream_t stream)
+{
+    if (B < 1 || B > ntraj_ || !dX || ldx < sz_.n) throw std::invalid_argument("x0_device: bad arguments");
+    if (!uploaded_) upload();
+    FgArgs a = args_;
+    a.X = dX; a.ldx = ldx; a.traj = d_traj_; a.B = B;
+    check(launch_x0(a, sz_.mission, dtype_, stream), "launch x0");
+}
+
+void batch::bounds_device(int B, void *dXlow, void *dXupp, long ldx, void *dFlow, void *dFupp, long ldf, hipStream_t stream)
+{
+    if (B < 1 || B > ntraj_ || !dXlow || !dXupp || !dFlow || !dFupp || ldx < sz_.n || ldf < sz_.neF)
+        throw std::invalid_argument("bounds_device: bad arguments");
+    if (!uploaded_) upload();
+    BoundsArgs a{};
+    a.xlow = dXlow; a.xupp = dXupp; a.ldx = ldx; a.Flow = dFlow; a.Fupp = dFupp; a.ldf = ldf;
+    a.traj = d_traj_; a.B = B; a.N = sz_.N; a.nb = sz_.nb; a.mission = sz_.mission;
+    a.dtmin = lm_.dtmin; a.dtmax = lm_.dtmax;
+    for (size_t i = 0; i < acs_.size(); ++i) {      // src/problem.cpp:272-285
+        const aircraft &c = acs_[i];
+        const double lo[11] = {lm_.xmin, lm_.ymin, lm_.zmin, c.Vamin, -c.gammamax, -1e20, -c.phimax, c.CLmin, -c.phidotmax, -c.phidotmax, c.Tmin};
+        const double up[11] = {lm_.xmax, lm_.ymax, lm_.zmax, c.Vamax, c.gammamax, 1e20, c.phimax, c.CLmax, c.phidotmax, c.phidotmax, c.Tmax};
+        for (int m = 0; m < 11; ++m) { a.ac[i].lo[m] = lo[m]; a.ac[i].up[m] = up[m]; }
+    }
+    check(launch_bounds(a, dtype_, stream), "launch bounds");
 }
 
 void batch::objectives(int B, const void *dF, long ldf, void *dObj, hipStream_t stream)
@@ -292,6 +346,12 @@ void problem::set_wind_table(const double *wind_enu)
     if (!dW_) check(hipMalloc(reinterpret_cast<void **>(&dW_), bytes), "hipMalloc(wind)");
     check(hipMemcpy(dW_, wind_enu, bytes, hipMemcpyHostToDevice), "hipMemcpy(wind)");
     eng_->set_windmodel(TOLFG_WIND_TABLE);
+    staged_ = false;
+}
+
+void problem::set_wind_grid(const tolfg_wind_grid &g)
+{
+    eng_->set_wind_grid(g);
     staged_ = false;
 }
 

@@ -44,6 +44,7 @@ public:
     const limit &limits() const { return lm_; }
     const snopt &snopt_params() const { return sn_; }
 
+    void set_wind_grid(const tolfg_wind_grid &g);      // uploads; switches to TOLFG_WIND_GRID
     void set_trajectories(int B, const tolfg_traj *trajs);
     int trajectories() const { return ntraj_; }
     const tolfg_traj &trajectory(int t) const { return host_traj_.at(t); }
@@ -54,6 +55,8 @@ public:
     void eval(int B, const void *dX, long ldx, void *dF, long ldf, void *dG, long ldg, const void *dWind,
               int needF, int needG, hipStream_t stream, void *dObj = nullptr);
     void objectives(int B, const void *dF, long ldf, void *dObj, hipStream_t stream);
+    void x0_device(int B, void *dX, long ldx, hipStream_t stream);
+    void bounds_device(int B, void *dXlow, void *dXupp, long ldx, void *dFlow, void *dFupp, long ldf, hipStream_t stream);
     // measurement aid: HIP events recorded on the launch stream around fg_kernel of every eval
     void set_timing(bool on);
     int kernel_time(double *avg_ms, double *min_ms);   // launches averaged since the last call
@@ -69,6 +72,7 @@ private:
     bool timing_ = false;
     std::vector<hipEvent_t> ev_;
     size_t ev_used_ = 0;
+    void *d_grid_ = nullptr;
     double *d_partial_ = nullptr;
     long partial_cap_ = 0;
     int ntraj_ = 0, cap_ = 0;
@@ -102,6 +106,7 @@ public:
     void evaluate(const double x[], bool needF, double F[], bool needG, double G[]);
 
     void set_wind_table(const double *wind_enu);   // [12][ts+1], ENU, reference member order
+    void set_wind_grid(const tolfg_wind_grid &g);  // wind model 3
     // ref: problem::writeJSON(filename), src/problem.cpp:1247 -- same keys, for the same consumers
     void writeJSON(const std::string &filename, const double *xsol, double final_cost) const;
 

@@ -29,6 +29,18 @@ def _enc(s):
     return None if s is None else str(s).encode()
 
 
+def _wind_grid(v, origin, spacing, datum):
+    """tolfg_wind_grid from a [nx][ny][nz] array of the north wind component (keeps the array alive)."""
+    v = np.ascontiguousarray(v, dtype=np.float64)
+    g = capi.WindGrid()
+    g.nx, g.ny, g.nz = v.shape
+    g.x0, g.y0, g.z0 = origin
+    g.dx, g.dy, g.dz = spacing
+    g.east_from_datum, g.north_from_datum, g.up_from_datum = datum
+    g.v = _d(v)
+    return g, v
+
+
 class Problem:
     """ref: `new problemS10(args)` / `new problemG7(args)` + what runSNOPT hands to SNOPT."""
 
@@ -98,6 +110,11 @@ class Problem:
         w = np.ascontiguousarray(wind_enu, dtype=np.float64)
         check(lib().tolfg_set_wind_table(self._h, _d(w)))
 
+    def set_wind_grid(self, v, origin, spacing=(150.0, 150.0, 150.0), datum=(0.0, 0.0, 0.0)):
+        """Wind model 3: gridded north wind component v[nx][ny][nz] on a regular ENU grid."""
+        g, keep = _wind_grid(v, origin, spacing, datum)
+        check(lib().tolfg_set_wind_grid(self._h, C.byref(g)))
+
     def write_json(self, filename, x, final_cost):
         """ref: problem::writeJSON -- the `snopt_results.json` the mission glue and MATLAB tools read."""
         x = np.ascontiguousarray(x, dtype=np.float64)
@@ -156,6 +173,7 @@ class Trajectory:
     radius_goal: float = 100.0
     xi: float = 0.0
     yi: float = 0.0
+    zi: float = 0.0
 
 
 class Batch:
@@ -209,9 +227,14 @@ class Batch:
         for t, tr in enumerate(trajs):
             arr[t].aircraft, arr[t].Vref, arr[t].href = tr.aircraft, tr.Vref, tr.href
             arr[t].north_goal, arr[t].east_goal, arr[t].radius_goal = tr.north_goal, tr.east_goal, tr.radius_goal
-            arr[t].xi, arr[t].yi = tr.xi, tr.yi
+            arr[t].xi, arr[t].yi, arr[t].zi = tr.xi, tr.yi, tr.zi
         check(lib().tolfg_batch_set_trajectories(self._h, len(trajs), arr))
         self.B = len(trajs)
+
+    def set_wind_grid(self, v, origin, spacing=(150.0, 150.0, 150.0), datum=(0.0, 0.0, 0.0)):
+        g, keep = _wind_grid(v, origin, spacing, datum)
+        check(lib().tolfg_batch_set_wind_grid(self._h, C.byref(g)))
+        self.windmodel = capi.WIND_GRID
 
     def x0(self, t, zi=0.0):
         x = np.zeros(self.n)
@@ -253,6 +276,23 @@ class Batch:
                                      G.data_ptr(), G.stride(0), None if wind is None else wind.data_ptr(),
                                      int(needF), int(needG), None if obj is None else obj.data_ptr(),
                                      C.c_void_p(stream)))
+
+    def x0_device(self, X, stream=None, B=None):
+        """Initial guess of trajectories [0,B) written into the rows of the device tensor X."""
+        import torch
+        B = X.shape[0] if B is None else B
+        if stream is None:
+            stream = torch.cuda.current_stream(X.device).cuda_stream
+        check(lib().tolfg_batch_x0_device(self._h, int(B), X.data_ptr(), X.stride(0), C.c_void_p(stream)))
+
+    def bounds_device(self, xlow, xupp, Flow, Fupp, stream=None, B=None):
+        import torch
+        B = xlow.shape[0] if B is None else B
+        assert xlow.stride(0) == xupp.stride(0) and Flow.stride(0) == Fupp.stride(0)
+        if stream is None:
+            stream = torch.cuda.current_stream(xlow.device).cuda_stream
+        check(lib().tolfg_batch_bounds_device(self._h, int(B), xlow.data_ptr(), xupp.data_ptr(), xlow.stride(0),
+                                              Flow.data_ptr(), Fupp.data_ptr(), Flow.stride(0), C.c_void_p(stream)))
 
     def objectives(self, F, out=None, stream=None, B=None):
         import torch
