@@ -60,6 +60,7 @@ struct FgArgs {
     int  tiles, nt;        // tiles per trajectory and nodes per tile, from plan_tiles()
     int  needF, needG;
     int  pattern;          // PATTERN_REFERENCE (104-entry slabs) | PATTERN_COMPACT (46-entry slabs)
+    int  waves_per_cu;     // cap on resident tile waves per CU (0 = whatever fits); host-side launch hint
     double *partial;       // [B*tiles][2] objective partials (sum T^2, sum (r-R)^2), device
     void   *obj;           // optional [B]: finalize_kernel also writes the objectives here, contiguous
     double kT, kp, kv, kdt;
@@ -99,6 +100,8 @@ hipError_t launch_bounds(const BoundsArgs &a, int dtype, hipStream_t s);
 
 // LDS bytes per workgroup of the fg kernel (for DESIGN.md / occupancy reporting)
 int fg_lds_bytes(int dtype);
+// LDS bytes to request at launch so that at most waves_per_cu workgroups share a CU (0 = no cap)
+int fg_lds_request(int dtype, int waves_per_cu);
 
 }  // namespace tolfg
 #endif

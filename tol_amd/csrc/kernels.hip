@@ -343,7 +343,10 @@ __global__ __launch_bounds__(TILE, TOLFG_MIN_WAVES_PER_SIMD) void fg_kernel(cons
     constexpr int GV = (PAT == PATTERN_COMPACT && VEC == 4) ? 2 : VEC;
     constexpr int SLABN = SlabGeom<PAT, GV>::SLABN;
     constexpr int NW = ((NI * TILE + 9 + VEC - 1) / VEC + TILE - 1) / TILE;   // window vectors per lane
-    __shared__ __attribute__((aligned(16))) T lds[TILE * RS];
+    // dynamic LDS: TILE*RS elements are used; the launch may request more to cap the waves per CU
+    // (fewer concurrent store streams suit the HBM write path better)
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    T *lds = reinterpret_cast<T *>(lds_raw);
     const int lane = threadIdx.x;
     const int N = a.N;
     // workgroup -> (trajectory, tile); consecutive workgroups walk the batch's memory in order
@@ -612,8 +615,9 @@ hipError_t launch_vec(const FgArgs &a, int vec, dim3 grid, hipStream_t s, hipEve
     constexpr int VMAX = 16 / sizeof(T);
     hipError_t e;
     if (t0 && (e = hipEventRecord(t0, s)) != hipSuccess) return e;
-    if (vec == VMAX) hipLaunchKernelGGL((fg_kernel<T, MISSION, WIND, VMAX, PAT>), grid, dim3(TILE), 0, s, a);
-    else             hipLaunchKernelGGL((fg_kernel<T, MISSION, WIND, 1, PAT>), grid, dim3(TILE), 0, s, a);
+    const unsigned lds = (unsigned)fg_lds_request(sizeof(T) == 8 ? 0 : 1, a.waves_per_cu);
+    if (vec == VMAX) hipLaunchKernelGGL((fg_kernel<T, MISSION, WIND, VMAX, PAT>), grid, dim3(TILE), lds, s, a);
+    else             hipLaunchKernelGGL((fg_kernel<T, MISSION, WIND, 1, PAT>), grid, dim3(TILE), lds, s, a);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (t1 && (e = hipEventRecord(t1, s)) != hipSuccess) return e;
@@ -832,5 +836,15 @@ hipError_t launch_bounds(const BoundsArgs &a, int dtype, hipStream_t s)
 }
 
 int fg_lds_bytes(int dtype) { return TILE * RS * (dtype == 0 ? 8 : 4); }
+
+int fg_lds_request(int dtype, int waves_per_cu)
+{
+    // LDS per workgroup such that at most `waves_per_cu` one-wave workgroups fit the CU's 160 KiB
+    const int need = fg_lds_bytes(dtype);
+    if (waves_per_cu <= 0) return need;
+    int cap = (160 * 1024 / waves_per_cu) & ~15;
+    if (cap > 64 * 1024) cap = 64 * 1024;
+    return cap > need ? cap : need;
+}
 
 }  // namespace tolfg

@@ -80,6 +80,13 @@ batch::batch(const std::string &mission, const std::string &root, const std::vec
     sz_ = make_sizes(mid, N, pattern);
 
     args_.pattern = pattern;
+    // Resident tile waves per CU (a launch-time LDS request caps it).  Fewer concurrent store streams
+    // suit the HBM write path, too few leave it idle.  Measured with bench.py on MI355X, B = 4096,
+    // ts = 200 (tools/occ_probe.sh): fp64 reference pattern, cap none(9) / 7 / 6 / 5 ->
+    // 5.13 / 5.57 / 5.63 / 5.53 TB/s; compact pattern none / 8 / 6 / 4 -> 5.32 / 5.48 / 4.94 / 4.45;
+    // fp32 none(16) / 12 / 8 / 6 -> 4.73 / 4.81 / 4.90 / 4.47.  TOLFG_WAVES_PER_CU overrides.
+    waves_per_cu_ = (dtype == TOLFG_F64 && pattern == PATTERN_REFERENCE) ? 6 : 8;
+    if (const char *e = std::getenv("TOLFG_WAVES_PER_CU")) waves_per_cu_ = std::atoi(e);
     args_.N = N;
     plan_tiles(N, dtype, &args_.tiles, &args_.nt);
     args_.c0 = sz_.c0;
@@ -186,6 +193,7 @@ void batch::eval(int B, const void *dX, long ldx, void *dF, long ldf, void *dG, 
     FgArgs a = args_;
     a.partial = d_partial_;
     a.obj = dObj;
+    a.waves_per_cu = waves_per_cu_;
     a.X = dX; a.ldx = ldx; a.F = dF; a.ldf = ldf; a.G = dG; a.ldg = ldg;
     a.wind = dWind; a.traj = d_traj_;
     a.B = B; a.needF = needF ? 1 : 0; a.needG = needG ? 1 : 0;

@@ -69,6 +69,7 @@ private:
     snopt sn_;
     int windmodel_, dtype_, device_;
     void upload();
+    int waves_per_cu_ = 6;
     bool timing_ = false;
     std::vector<hipEvent_t> ev_;
     size_t ev_used_ = 0;

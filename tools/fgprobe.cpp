@@ -66,6 +66,7 @@ int main(int argc, char **argv)
     a.kT = 0; a.kp = 8; a.kv = 0; a.kdt = 1;
     a.ac[0] = tolfg::AcCoef{1.0 / 6.1228, 1.2682 * 0.6316 / (2 * 6.1228), 0.03, 1.0 / (16.4457 * M_PI * 0.9693)};
     a.stamps = dS; a.variant = variant;
+    a.waves_per_cu = argc > 5 ? atoi(argv[5]) : 0;
 
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -78,8 +79,8 @@ int main(int argc, char **argv)
     CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     const double bytes = 8.0 * B * ((double)n + neF + neG);
-    printf("B=%d N=%d variant=%d: %.2f us/launch  %.1f GB/s algorithmic (stamped build, not a benchmark)\n", B, N,
-           variant, 1e3 * ms / reps, bytes / (1e6 * ms / reps));
+    printf("B=%d N=%d variant=%d waves/CU cap %d: %.2f us/launch  %.1f GB/s algorithmic (stamped build, not a benchmark)\n", B, N,
+           variant, a.waves_per_cu, 1e3 * ms / reps, bytes / (1e6 * ms / reps));
 
     std::vector<unsigned long long> S((size_t)10 * blocks);
     CK(hipMemcpy(S.data(), dS, sizeof(unsigned long long) * S.size(), hipMemcpyDeviceToHost));
