@@ -3,6 +3,8 @@
 
 #include <dlfcn.h>
 
+#include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -320,6 +322,7 @@ void problem::ensure_device()
     if (device_ready_) return;
     if (const char *e = std::getenv("TOLFG_CALLBACK_STAGING")) zero_copy_ = !(e[0] == '1');
     if (const char *e = std::getenv("TOLFG_ZERO_COPY_LIMIT")) zero_copy_limit_ = (size_t)std::atol(e);
+    if (const char *e = std::getenv("TOLFG_CHUNKS")) nchunks_ = std::min(kChunks, std::max(1, std::atoi(e)));
     check(hipSetDevice(eng_->device()), "hipSetDevice");
     if (!stream_) check(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking), "hipStreamCreate");
     if (!hx_) check(hipHostMalloc(reinterpret_cast<void **>(&hx_), sizeof(double) * ldx_, hipHostMallocDefault), "hipHostMalloc");
@@ -328,6 +331,8 @@ void problem::ensure_device()
     if (!dX_) check(hipMalloc(reinterpret_cast<void **>(&dX_), sizeof(double) * ldx_), "hipMalloc");
     if (!dF_) check(hipMalloc(reinterpret_cast<void **>(&dF_), sizeof(double) * ldf_), "hipMalloc");
     if (!dG_) check(hipMalloc(reinterpret_cast<void **>(&dG_), sizeof(double) * ldg_), "hipMalloc");
+    for (int c = 0; c < kChunks; ++c)
+        if (!chunk_ev_[c]) check(hipEventCreateWithFlags(&chunk_ev_[c], hipEventDisableTiming), "hipEventCreate");
     device_ready_ = true;
 }
 
@@ -342,6 +347,7 @@ problem::~problem()
     if (dF_) (void)hipFree(dF_);
     if (dG_) (void)hipFree(dG_);
     if (dW_) (void)hipFree(dW_);
+    for (int c = 0; c < kChunks; ++c) if (chunk_ev_[c]) (void)hipEventDestroy(chunk_ev_[c]);
     if (stream_) (void)hipStreamDestroy(stream_);
 }
 
@@ -381,13 +387,31 @@ void problem::stage_and_launch(const double xin[], bool needF, bool needG)
         check(hipMemcpyAsync(dX_, hx_, sizeof(double) * n, hipMemcpyHostToDevice, stream_), "H2D x");
         eng_->eval(1, dX_, ldx_, dF_, ldf_, dG_, ldg_, dW_, needF, needG, stream_);
         if (needF) check(hipMemcpyAsync(hF_, dF_, sizeof(double) * neF, hipMemcpyDeviceToHost, stream_), "D2H F");
-        if (needG) check(hipMemcpyAsync(hG_, dG_, sizeof(double) * neG, hipMemcpyDeviceToHost, stream_), "D2H G");
+        if (needG) {
+            // G comes back in a few pieces, each followed by an event, so that collect() can copy
+            // piece i into the caller's array while piece i+1 is still crossing PCIe
+            for (int c = 0; c < nchunks_; ++c) {
+                const size_t lo = (size_t)neG * c / nchunks_, hi = (size_t)neG * (c + 1) / nchunks_;
+                check(hipMemcpyAsync(hG_ + lo, dG_ + lo, sizeof(double) * (hi - lo), hipMemcpyDeviceToHost, stream_), "D2H G");
+                check(hipEventRecord(chunk_ev_[c], stream_), "hipEventRecord");
+            }
+        }
     }
+    chunked_ = !direct && needG;
     staged_ = true; haveF_ = needF; haveG_ = needG;
 }
 
 void problem::collect(bool wantF, double F[], bool wantG, double G[])
 {
+    if (wantG && chunked_) {
+        for (int c = 0; c < nchunks_; ++c) {
+            const size_t lo = (size_t)neG * c / nchunks_, hi = (size_t)neG * (c + 1) / nchunks_;
+            check(hipEventSynchronize(chunk_ev_[c]), "hipEventSynchronize");
+            if (c == 0 && wantF) std::memcpy(F, hF_, sizeof(double) * neF);     // F's copy precedes G's on the stream
+            std::memcpy(G + lo, hG_ + lo, sizeof(double) * (hi - lo));
+        }
+        return;
+    }
     check(hipStreamSynchronize(stream_), "stream sync");
     if (wantF) std::memcpy(F, hF_, sizeof(double) * neF);
     if (wantG) std::memcpy(G, hG_, sizeof(double) * neG);
@@ -406,6 +430,22 @@ void problem::evaluate(const double xin[], bool needF, double F[], bool needG, d
 {
     if (debug) dump("Xoutput.txt", xin, n);
     if (!needF && !needG) return;
+    static const bool trace = std::getenv("TOLFG_TRACE") != nullptr;     // one line per call on stderr
+    if (trace) {
+        using clk = std::chrono::steady_clock;
+        const auto t0 = clk::now();
+        stage_and_launch(xin, needF, needG);
+        const auto t1 = clk::now();
+        check(hipStreamSynchronize(stream_), "stream sync");
+        const auto t2 = clk::now();
+        collect(needF, F, needG, G);
+        const auto t3 = clk::now();
+        auto us = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+        std::fprintf(stderr, "tolfg trace: stage+launch %.1f us, wait %.1f us, copy out %.1f us\n", us(t0, t1), us(t1, t2), us(t2, t3));
+        if (debug && needF) dump("Foutput.txt", F, neF);
+        if (debug && needG) dump("Goutput.txt", G, neG);
+        return;
+    }
     stage_and_launch(xin, needF, needG);
     collect(needF, F, needG, G);
     if (debug && needF) dump("Foutput.txt", F, neF);

@@ -138,6 +138,10 @@ private:
     void dump(const char *name, const double *v, int len);
 
     hipStream_t stream_ = nullptr;
+    static constexpr int kChunks = 6;               // pieces of G's device-to-host copy (staged path)
+    hipEvent_t chunk_ev_[kChunks] = {};
+    bool chunked_ = false;
+    int nchunks_ = 2;               // measured at ts=2000: 1 / 2 / 4 / 6 pieces -> 213 / 169 / 177 / 237 us per call
     double *hx_ = nullptr, *hF_ = nullptr, *hG_ = nullptr;      // pinned
     double *dX_ = nullptr, *dF_ = nullptr, *dG_ = nullptr, *dW_ = nullptr;
     long ldx_, ldf_, ldg_;
