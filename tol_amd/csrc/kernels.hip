@@ -92,7 +92,28 @@ __device__ __forceinline__ float sqrt_t(float a) { return sqrtf(a); }
 template <typename V>
 __device__ __forceinline__ void stream_store(V *p, V v)
 {
-#ifdef TOLFG_NT_STORES
+#if defined(TOLFG_STORE_FLAVOR)
+    // cache-policy experiments (tools/fgprobe.cpp): 16-byte stores with explicit sc0/sc1/nt bits
+    if constexpr (sizeof(V) == 16) {
+        typedef unsigned u4 __attribute__((ext_vector_type(4)));
+        const u4 d = __builtin_bit_cast(u4, v);
+        asm volatile("global_store_dwordx4 %0, %1, off " TOLFG_STORE_FLAVOR : : "v"(p), "v"(d) : "memory");
+    } else {
+        *p = v;
+    }
+#elif defined(TOLFG_NT_STORES)
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+
+// Defects and objective-gradient entries are 16/8-byte pieces that consecutive instructions of the
+// same wave complete into whole lines inside L2; TOLFG_NT_SMALL makes them non-temporal too (A/B).
+template <typename V>
+__device__ __forceinline__ void small_store(V *p, V v)
+{
+#ifdef TOLFG_NT_SMALL
     __builtin_nontemporal_store(v, p);
 #else
     *p = v;
@@ -317,11 +338,11 @@ __device__ __forceinline__ void store_defects(T *p, const T (&d)[8])
 {
     if constexpr (VEC == 2) {
         typedef typename Vec<T, 2>::type v2;
-        p[0] = d[0];
-        *reinterpret_cast<v2 *>(p + 1) = v2{d[1], d[2]};
-        *reinterpret_cast<v2 *>(p + 3) = v2{d[3], d[4]};
-        *reinterpret_cast<v2 *>(p + 5) = v2{d[5], d[6]};
-        p[7] = d[7];
+        small_store(p, d[0]);
+        small_store(reinterpret_cast<v2 *>(p + 1), v2{d[1], d[2]});
+        small_store(reinterpret_cast<v2 *>(p + 3), v2{d[3], d[4]});
+        small_store(reinterpret_cast<v2 *>(p + 5), v2{d[5], d[6]});
+        small_store(p + 7, d[7]);
     } else if constexpr (VEC == 4) {
         typedef typename Vec<T, 2>::type v2;
         typedef typename Vec<T, 4>::type v4;
@@ -430,9 +451,9 @@ __global__ __launch_bounds__(TILE, TOLFG_MIN_WAVES_PER_SIMD) void fg_kernel(cons
         if (act) sumP = d * d;
         if (a.needG && act && !(TOLFG_VARIANT(a) & 1024)) {
             T *gc = Grow + 1 + 3 * (k0 + lane);
-            gc[0] = kp * d * dx / r;
-            gc[1] = kp * d * dy / r;
-            gc[2] = kT * s[10];
+            small_store(gc + 0, kp * d * dx / r);
+            small_store(gc + 1, kp * d * dy / r);
+            small_store(gc + 2, kT * s[10]);
         }
     } else {
         // src/problemG7.cpp:364-368: one thrust entry per node, after (dt, x0, y0)
