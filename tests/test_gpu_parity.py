@@ -146,3 +146,32 @@ def test_batch_matches_oracle(tolfg, oracle, mission, dtype, pad):
         assert_close(F[t], Fo, tol=tol, what=f"batch {mission} {dtype} F[{t}]")
         assert_close(G[t], Go, tol=tol, mask=oprobs[t].undefined_mask(), what=f"batch {mission} {dtype} G[{t}]")
     assert_close(obj.double().cpu().numpy(), F[:, 0], tol=0.0, what="objectives gather")
+
+
+def test_eval_is_graph_capturable(tolfg, oracle):
+    """After one warm call (workspace allocation, trajectory upload) tolfg_batch_eval only enqueues
+    kernels, so a caller may capture it into a hipGraph and replay it (launch-bound inner loops)."""
+    import torch
+    N, B = 200, 16
+    bt = tolfg.Batch("S10", ["tempest"], ts=N)
+    bt.set_trajectories([tolfg.Trajectory(Vref=1.0 + t) for t in range(B)])
+    ops = [oracle.Problem("S10", "tempest", N=N, Vref=1.0 + t) for t in range(B)]
+    X = np.stack([oracle.perturbed(ops[t], 500 + t) for t in range(B)])
+    dX, dF, dG = bt.alloc(B)
+    obj = torch.zeros(B, dtype=torch.float64, device="cuda")
+    dX[:, :bt.n] = torch.from_numpy(X).cuda()
+    bt.eval(dX, dF, dG, obj=obj)                      # warm call outside the capture
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        bt.eval(dX, dF, dG, obj=obj)
+    X2 = np.stack([oracle.perturbed(ops[t], 900 + t) for t in range(B)])
+    dX[:, :bt.n] = torch.from_numpy(X2).cuda()        # new inputs, same buffers
+    dF.zero_(); dG.zero_(); obj.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    for t in (0, 7, 15):
+        Fo, Go = ops[t].eval(X2[t])
+        assert_close(dF[t, :bt.neF].cpu().numpy(), Fo, what="graph F")
+        assert_close(dG[t, :bt.neG].cpu().numpy(), Go, mask=ops[t].undefined_mask(), what="graph G")
+    assert np.array_equal(obj.cpu().numpy(), dF[:, 0].cpu().numpy())
