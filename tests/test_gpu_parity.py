@@ -175,3 +175,39 @@ def test_eval_is_graph_capturable(tolfg, oracle):
         assert_close(dF[t, :bt.neF].cpu().numpy(), Fo, what="graph F")
         assert_close(dG[t, :bt.neG].cpu().numpy(), Go, mask=ops[t].undefined_mask(), what="graph G")
     assert np.array_equal(obj.cpu().numpy(), dF[:, 0].cpu().numpy())
+
+
+def test_unguarded_divisions_propagate_like_the_reference(tolfg, oracle):
+    """cost() divides by r_k (S10) / dist (G7) unguarded, so a node on
+    the goal centre or a closed G7 leg yields inf/nan.  The HIP path must produce non-finite values
+    in exactly the entries where the oracle does, and agree everywhere else."""
+    N = 64
+    # S10: put node 10 exactly on the goal centre -> r = 0 -> 0/0 in its two objective-gradient entries
+    o = oracle.Problem("S10", "tempest", N=N, east_goal=400.0, north_goal=0.0)
+    p = tolfg.Problem("S10", "tempest", ts=N, east_goal=400.0, north_goal=0.0)
+    x = oracle.perturbed(o, 4)
+    x[11 * 10 + 1], x[11 * 10 + 2] = 0.0, 400.0
+    F, G, st = p.define_fg(x)
+    Fo, Go = o.eval(x)
+    assert st == 1
+    assert np.array_equal(np.isfinite(G), np.isfinite(Go)) and np.array_equal(np.isfinite(F), np.isfinite(Fo))
+    bad = ~np.isfinite(Go)
+    assert bad.sum() == 2 and set(np.flatnonzero(bad)) == {1 + 3 * 10, 2 + 3 * 10}
+    assert_close(np.where(bad, 0.0, G), np.where(bad, 0.0, Go), mask=o.undefined_mask(), what="S10 r=0 G")
+    assert_close(F, Fo, what="S10 r=0 F")
+    p.close()
+    # G7: last node on top of the first -> dist = 0
+    o = oracle.Problem("G7", "tempest", N=N, radius_goal=0.0, gains=[100.0, 0.5, 0.5, 0.0, 0.0])
+    p = tolfg.Problem("G7", "tempest", ts=N, radius_goal=0.0)
+    x = oracle.perturbed(o, 5)
+    x[11 * N + 1], x[11 * N + 2] = x[1], x[2]
+    F, G, st = p.define_fg(x)
+    o_ship = oracle.Problem("G7", "tempest", N=N, radius_goal=0.0)     # shipped gains (kp = kv = 0), like the product
+    Fo, Go = o_ship.eval(x)
+    assert st == 1
+    assert np.array_equal(np.isnan(G), np.isnan(Go)) and np.array_equal(np.isinf(G), np.isinf(Go))
+    assert np.array_equal(np.isnan(F), np.isnan(Fo)) and np.array_equal(np.isinf(F), np.isinf(Fo))
+    assert (~np.isfinite(Go)).sum() > 0
+    ok = np.isfinite(Go)
+    assert_close(np.where(ok, G, 0.0), np.where(ok, Go, 0.0), what="G7 dist=0 G")
+    p.close()
