@@ -70,6 +70,13 @@ def cpu_baseline(args, seconds):
             n += 1
         dt = time.perf_counter() - t0
         out[opt] = (n * args.ts / dt, n, dt)
+    # fused per-node form on one core (variant b)
+    o.eval(x)
+    n1, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds / 6:
+        o.eval(x)
+        n1 += 1
+    fused1 = n1 * args.ts / (time.perf_counter() - t0)
     # fused per-node form, all host cores, OpenMP over trajectories
     # worker pool sized to the GPU box's CPU share (16 per GPU), not to every core the host shows
     cores = int(os.environ.get("TOLFG_CPU_THREADS", min(len(os.sched_getaffinity(0)), 16)))
@@ -87,6 +94,7 @@ def cpu_baseline(args, seconds):
             "sample": f"{out['O2'][1]} evaluations of one {args.mission}/{args.aircraft}/ts={args.ts} trajectory "
                       f"in {out['O2'][2]:.1f} s, reference evaluation order (entry-wise Jacobian), gcc -O2",
             "value_O0": out["O0"][0],
+            "fused_one_core": {"value": fused1, "cores": 1, "sample": f"{n1} evaluations, per-node fused form, gcc -O2"},
             "fused_all_cores": {"value": fused, "cores": used, "sample": f"{n} x {Bc} trajectories, per-node fused form, OpenMP"}}
     return base
 
