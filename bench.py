@@ -182,7 +182,10 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            try:      # eager communicator creation on this rank's GPU (RCCL over xGMI)
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            except TypeError:
+                dist.init_process_group("nccl")
         else:
             dist.init_process_group("gloo")
 
@@ -213,7 +216,10 @@ def main():
                 pending[s] = None
         torch.cuda.synchronize()
         if world > 1:
-            dist.barrier()
+            if args.backend == "nccl":
+                dist.barrier(device_ids=[local])
+            else:
+                dist.barrier()
             torch.cuda.synchronize()
 
     for i in range(args.warmup):
@@ -283,7 +289,7 @@ def main():
         print(json.dumps(line), flush=True)
 
     if world > 1:
-        dist.barrier()
+        fence()
         dist.destroy_process_group()
 
 
