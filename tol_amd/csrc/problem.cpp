@@ -88,7 +88,7 @@ batch::batch(const std::string &mission, const std::string &root, const std::vec
     // 5.13 / 5.57 / 5.63 / 5.53 TB/s; compact pattern none / 8 / 6 / 4 -> 5.32 / 5.48 / 4.94 / 4.45;
     // fp32 none(16) / 12 / 8 / 6 -> 4.73 / 4.81 / 4.90 / 4.47.  TOLFG_WAVES_PER_CU overrides.
     waves_per_cu_ = (dtype == TOLFG_F64 && pattern == PATTERN_REFERENCE) ? 6 : 8;
-    if (const char *e = std::getenv("TOLFG_WAVES_PER_CU")) waves_per_cu_ = std::atoi(e);
+    if (const char *e = std::getenv("TOLFG_WAVES_PER_CU")) { waves_per_cu_ = std::atoi(e); waves_forced_ = true; }
     args_.N = N;
     plan_tiles(N, dtype, &args_.tiles, &args_.nt);
     args_.c0 = sz_.c0;
@@ -195,7 +195,11 @@ void batch::eval(int B, const void *dX, long ldx, void *dF, long ldf, void *dG, 
     FgArgs a = args_;
     a.partial = d_partial_;
     a.obj = dObj;
-    a.waves_per_cu = waves_per_cu_;
+    // The cap pays only when the output stream really goes to HBM; a batch whose F and G fit the
+    // 256 MiB Infinity Cache is served on-die and wants every wave it can get (B = 1024, ts = 200:
+    // 4.3 TB/s capped, 5.5 TB/s uncapped).
+    const double out_bytes = (double)elem_size() * B * ((needF ? sz_.neF : 0) + (needG ? sz_.neG : 0));
+    a.waves_per_cu = (waves_forced_ || out_bytes > 192.0 * 1024 * 1024) ? waves_per_cu_ : 0;
     a.X = dX; a.ldx = ldx; a.F = dF; a.ldf = ldf; a.G = dG; a.ldg = ldg;
     a.wind = dWind; a.traj = d_traj_;
     a.B = B; a.needF = needF ? 1 : 0; a.needG = needG ? 1 : 0;

@@ -70,6 +70,7 @@ private:
     int windmodel_, dtype_, device_;
     void upload();
     int waves_per_cu_ = 6;
+    bool waves_forced_ = false;
     bool timing_ = false;
     std::vector<hipEvent_t> ev_;
     size_t ev_used_ = 0;
