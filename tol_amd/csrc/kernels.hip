@@ -391,7 +391,11 @@ __global__ __launch_bounds__(TILE, TOLFG_MIN_WAVES_PER_SIMD) void fg_kernel(cons
 #pragma unroll
         for (int j = 0; j < NW; j++) {
             const int i = lane + TILE * j;
+#ifdef TOLFG_NT_LOADS
+            if (i < nvec) win[j] = __builtin_nontemporal_load(reinterpret_cast<const vec *>(xwin + (long)i * VEC));
+#else
             if (i < nvec) win[j] = *reinterpret_cast<const vec *>(xwin + (long)i * VEC);
+#endif
         }
 #pragma unroll
         for (int j = 0; j < NW; j++) {
