@@ -87,7 +87,9 @@ batch::batch(const std::string &mission, const std::string &root, const std::vec
     // ts = 200 (tools/occ_probe.sh): fp64 reference pattern, cap none(9) / 7 / 6 / 5 ->
     // 5.13 / 5.57 / 5.63 / 5.53 TB/s; compact pattern none / 8 / 6 / 4 -> 5.32 / 5.48 / 4.94 / 4.45;
     // fp32 none(16) / 12 / 8 / 6 -> 4.73 / 4.81 / 4.90 / 4.47.  TOLFG_WAVES_PER_CU overrides.
-    waves_per_cu_ = (dtype == TOLFG_F64 && pattern == PATTERN_REFERENCE) ? 6 : 8;
+    // With the inputs read from HBM each step (bench.py --x-buffers 4): 5 / 6 / 7 / 8 / none ->
+    // 4.96 / 5.13 / 5.20 / 5.10 / 5.01 TB/s, so 7.
+    waves_per_cu_ = (dtype == TOLFG_F64 && pattern == PATTERN_REFERENCE) ? 7 : 8;
     if (const char *e = std::getenv("TOLFG_WAVES_PER_CU")) { waves_per_cu_ = std::atoi(e); waves_forced_ = true; }
     args_.N = N;
     plan_tiles(N, dtype, &args_.tiles, &args_.nt);

@@ -69,7 +69,7 @@ private:
     snopt sn_;
     int windmodel_, dtype_, device_;
     void upload();
-    int waves_per_cu_ = 6;
+    int waves_per_cu_ = 7;
     bool waves_forced_ = false;
     bool timing_ = false;
     std::vector<hipEvent_t> ev_;
