@@ -100,16 +100,28 @@ def cpu_baseline(args, seconds):
 
 
 def callback_mode(tol_amd, mission, aircraft, ts, calls):
-    """Single-trajectory SNOPT-callback rate: host x -> host F, G through DEFINEGusrfg_."""
+    """Single-trajectory SNOPT-callback rate: host x -> host F, G through DEFINEGusrfg_, entered the
+    way snOptA does (all arguments by reference, prepared once: the loop times the C ABI, not the
+    construction of ctypes objects)."""
+    import ctypes as C
     p = tol_amd.Problem(mission, aircraft, ts=ts)
-    x = p.x0()
-    for _ in range(10):
-        p.define_fg(x)
+    p.make_current()
+    L = tol_amd.lib()
+    dp = C.POINTER(C.c_double)
+    x = np.ascontiguousarray(p.x0())
+    F, G = np.zeros(p.neF), np.zeros(p.neG)
+    st, n, neF, neG = C.c_int(1), C.c_int(p.n), C.c_int(p.neF), C.c_int(p.neG)
+    one, zero = C.c_int(1), C.c_int(0)
+    argv = (C.byref(st), C.byref(n), x.ctypes.data_as(dp), C.byref(one), C.byref(neF), F.ctypes.data_as(dp),
+            C.byref(one), C.byref(neG), G.ctypes.data_as(dp), None, C.byref(zero), None, C.byref(zero), None, C.byref(zero))
+    fn = L.DEFINEGusrfg_
+    for _ in range(50):
+        fn(*argv)
     t0 = time.perf_counter()
     for _ in range(calls):
-        F, G, st = p.define_fg(x)
+        fn(*argv)
     dt = time.perf_counter() - t0
-    assert st == 1
+    assert st.value == 1 and np.isfinite(F).all()
     p.close()
     return {"workload": f"{mission}/{aircraft}/ts={ts} single trajectory, DEFINEGusrfg_ host->host",
             "us_per_call": 1e6 * dt / calls, "node_evals_per_s": calls * ts / dt, "calls": calls}
