@@ -171,6 +171,7 @@ def main():
     ap.add_argument("--x-buffers", type=int, default=4,
                     help="distinct input batches rotated over the steps; 4 x 72 MB exceed the 256 MiB Infinity "
                          "Cache, so every step reads its X from HBM rather than from a cache that kept it")
+    ap.add_argument("--ld-pad", type=int, default=0, help="pad the row strides of X, F, G to this many elements (0 = 16 bytes)")
     ap.add_argument("--pattern", default="reference", choices=["reference", "compact"],
                     help="Jacobian sparsity pattern; the headline metric is quoted on the reference's own pattern")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -207,7 +208,7 @@ def main():
     B = args.batch
     bt = tol_amd.Batch(args.mission, (args.aircraft,), ts=args.ts, dtype=args.dtype, device=local, pattern=args.pattern)
     _, X = make_inputs(bt, tol_amd, B, first_index=rank * B)
-    dX, dF, dG = bt.alloc(B)
+    dX, dF, dG = bt.alloc(B, pad=(args.ld_pad or None))
     dX[:, :bt.n] = torch.from_numpy(X).to(bt.torch_dtype()).cuda()
     del X
     # further input batches: the same trajectories, the decision vectors rotated by whole rows
