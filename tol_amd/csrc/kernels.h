@@ -61,6 +61,7 @@ struct FgArgs {
     int  needF, needG;
     int  pattern;          // PATTERN_REFERENCE (104-entry slabs) | PATTERN_COMPACT (46-entry slabs)
     int  waves_per_cu;     // cap on resident tile waves per CU (0 = whatever fits); host-side launch hint
+    int  single;           // 1 = one workgroup per trajectory, one launch (tiles <= 8, small B)
     double *partial;       // [B*tiles][2] objective partials (sum T^2, sum (r-R)^2), device
     void   *obj;           // optional [B]: finalize_kernel also writes the objectives here, contiguous
     double kT, kp, kv, kdt;

@@ -356,22 +356,17 @@ __device__ __forceinline__ void store_defects(T *p, const T (&d)[8])
     }
 }
 
+// One tile: everything a wavefront does for `cnt` consecutive nodes of trajectory b.  lds is the
+// wave's own TILE*RS-element region; sumT / sumP return the tile's objective terms (wave-uniform).
 template <typename T, int MISSION, int WIND, int VEC, int PAT>
-__global__ __launch_bounds__(TILE, TOLFG_MIN_WAVES_PER_SIMD) void fg_kernel(const FgArgs a)
+__device__ __forceinline__ void tile_body(const FgArgs &a, T *lds, int item, int lane, T &sumT_out, T &sumP_out)
 {
     typedef typename Vec<T, VEC>::type vec;
     // slab stores: 16 bytes per lane where the slab length allows (46 floats are 23 pairs, not quads)
     constexpr int GV = (PAT == PATTERN_COMPACT && VEC == 4) ? 2 : VEC;
     constexpr int SLABN = SlabGeom<PAT, GV>::SLABN;
     constexpr int NW = ((NI * TILE + 9 + VEC - 1) / VEC + TILE - 1) / TILE;   // window vectors per lane
-    // dynamic LDS: TILE*RS elements are used; the launch may request more to cap the waves per CU
-    // (fewer concurrent store streams suit the HBM write path better, DESIGN.md section 6)
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    T *lds = reinterpret_cast<T *>(lds_raw);
-    const int lane = threadIdx.x;
     const int N = a.N;
-    // workgroup -> (trajectory, tile); consecutive workgroups walk the batch's memory in order
-    const int item = blockIdx.x;
     const int b = item / a.tiles;
     const int k0 = (item - b * a.tiles) * a.nt;
     const int cnt = min(a.nt, N - k0);
@@ -466,11 +461,9 @@ __global__ __launch_bounds__(TILE, TOLFG_MIN_WAVES_PER_SIMD) void fg_kernel(cons
     if (a.needF) {
         sumT = wave_sum(sumT);
         sumP = wave_sum(sumP);
-        if (lane == 0) {
-            a.partial[2 * (long)item + 0] = (double)sumT;
-            a.partial[2 * (long)item + 1] = (double)sumP;
-        }
     }
+    sumT_out = sumT;
+    sumP_out = sumP;
 
     if (a.needG) {
         T *row = lds + lane * RS;
@@ -498,15 +491,31 @@ __global__ __launch_bounds__(TILE, TOLFG_MIN_WAVES_PER_SIMD) void fg_kernel(cons
 #endif
 }
 
+// fg_kernel: one 64-lane workgroup per tile; consecutive workgroups walk the batch's memory in order.
+template <typename T, int MISSION, int WIND, int VEC, int PAT>
+__global__ __launch_bounds__(TILE, TOLFG_MIN_WAVES_PER_SIMD) void fg_kernel(const FgArgs a)
+{
+    // dynamic LDS: TILE*RS elements are used; the launch may request more to cap the waves per CU
+    // (fewer concurrent store streams suit the HBM write path better, DESIGN.md section 6)
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const int lane = threadIdx.x;
+    const int item = blockIdx.x;
+    T sumT, sumP;
+    tile_body<T, MISSION, WIND, VEC, PAT>(a, reinterpret_cast<T *>(lds_raw), item, lane, sumT, sumP);
+    if (a.needF && lane == 0) {
+        a.partial[2 * (long)item + 0] = (double)sumT;
+        a.partial[2 * (long)item + 1] = (double)sumP;
+    }
+}
+
 // One wavefront per trajectory, lanes = output entries: objective value, the last node's
 // objective-gradient entries, boundary rows and their gradients.  O(1) per trajectory except the
 // in-order sum over the tiles' objective partials (deterministic, no atomics).
+// sumT / sumP: the objective terms of nodes 0..N-1, already added up in tile order.
 template <typename T, int MISSION, int PAT>
-__global__ __launch_bounds__(TILE) void finalize_kernel(const FgArgs a)
+__device__ __forceinline__ void finalize_body(const FgArgs &a, int b, int lane, T sumT, T sumP)
 {
     constexpr int SLABN = PAT == PATTERN_COMPACT ? SLAB_COMPACT : SLAB_FULL;
-    const int b = blockIdx.x;
-    const int lane = threadIdx.x;
     const int N = a.N;
     const T *x = static_cast<const T *>(a.X) + (long)b * a.ldx;
     T *F = static_cast<T *>(a.F) + (long)b * a.ldf;
@@ -517,15 +526,7 @@ __global__ __launch_bounds__(TILE) void finalize_kernel(const FgArgs a)
     const T TN = x[NI * N + 11];
     const long gb = a.c0 + (long)SLABN * N;         // first boundary-row entry
 
-    T sumT = T(0), sumP = T(0);
-    if (a.needF) {
-        const double *part = a.partial + 2 * (long)b * a.tiles;
-        for (int t = 0; t < a.tiles; t++) {
-            sumT += T(part[2 * t + 0]);
-            sumP += T(part[2 * t + 1]);
-        }
-        sumT += TN * TN;
-    }
+    if (a.needF) sumT += TN * TN;
 
     if constexpr (MISSION == MISSION_S10) {
         const T dx = x[NI * N + 1] - T(tr.xg), dy = x[NI * N + 2] - T(tr.yg);
@@ -627,6 +628,45 @@ __global__ __launch_bounds__(TILE) void finalize_kernel(const FgArgs a)
     }
 }
 
+template <typename T, int MISSION, int PAT>
+__global__ __launch_bounds__(TILE) void finalize_kernel(const FgArgs a)
+{
+    const int b = blockIdx.x;
+    T sumT = T(0), sumP = T(0);
+    if (a.needF) {
+        const double *part = a.partial + 2 * (long)b * a.tiles;
+        for (int t = 0; t < a.tiles; t++) {
+            sumT += T(part[2 * t + 0]);
+            sumP += T(part[2 * t + 1]);
+        }
+    }
+    finalize_body<T, MISSION, PAT>(a, b, threadIdx.x, sumT, sumP);
+}
+
+// Whole trajectories in one workgroup (ts <= 512): wave w evaluates tile w, the tiles' objective
+// terms meet in LDS, wave 0 finalizes.  One launch instead of two and no workspace round trip --
+// what the latency-bound SNOPT callback wants; the batched path keeps fg_kernel + finalize_kernel
+// because waves that start together stay in phase and stream worse.
+template <typename T, int MISSION, int WIND, int VEC, int PAT>
+__global__ __launch_bounds__(8 * TILE) void fg_single_kernel(const FgArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    T *lds = reinterpret_cast<T *>(lds_raw);
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x / TILE), lane = threadIdx.x % TILE;   // w is wave-uniform: keep it scalar
+    const int b = blockIdx.x;
+    double *red = reinterpret_cast<double *>(lds + (long)a.tiles * TILE * RS);     // [tiles][2]
+    T sumT, sumP;
+    tile_body<T, MISSION, WIND, VEC, PAT>(a, lds + (long)w * TILE * RS, b * a.tiles + w, lane, sumT, sumP);
+    if (lane == 0) { red[2 * w] = (double)sumT; red[2 * w + 1] = (double)sumP; }
+    __syncthreads();
+    if (w == 0) {
+        T st = T(0), sp = T(0);
+        if (a.needF)
+            for (int t = 0; t < a.tiles; t++) { st += T(red[2 * t]); sp += T(red[2 * t + 1]); }
+        finalize_body<T, MISSION, PAT>(a, b, lane, st, sp);
+    }
+}
+
 template <typename T>
 __global__ void objectives_kernel(const T *F, long ldf, T *obj, int B)
 {
@@ -639,6 +679,23 @@ hipError_t launch_vec(const FgArgs &a, int vec, dim3 grid, hipStream_t s, hipEve
 {
     constexpr int VMAX = 16 / sizeof(T);
     hipError_t e;
+    if (a.single) {
+        // one workgroup per trajectory, one launch (the callback path)
+        const unsigned ldsz = (unsigned)(a.tiles * TILE * RS * sizeof(T) + 16 * a.tiles);
+        const dim3 g1(a.B), b1(TILE * a.tiles);
+        if (t0 && (e = hipEventRecord(t0, s)) != hipSuccess) return e;
+        if (vec == VMAX) {
+            auto kf = fg_single_kernel<T, MISSION, WIND, VMAX, PAT>;
+            if (ldsz > 64 * 1024 && (e = hipFuncSetAttribute(reinterpret_cast<const void *>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, ldsz)) != hipSuccess) return e;
+            hipLaunchKernelGGL(kf, g1, b1, ldsz, s, a);
+        } else {
+            auto kf = fg_single_kernel<T, MISSION, WIND, 1, PAT>;
+            if (ldsz > 64 * 1024 && (e = hipFuncSetAttribute(reinterpret_cast<const void *>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, ldsz)) != hipSuccess) return e;
+            hipLaunchKernelGGL(kf, g1, b1, ldsz, s, a);
+        }
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        return t1 ? hipEventRecord(t1, s) : hipSuccess;
+    }
     if (t0 && (e = hipEventRecord(t0, s)) != hipSuccess) return e;
     const unsigned lds = (unsigned)fg_lds_request(sizeof(T) == 8 ? 0 : 1, a.waves_per_cu);
     if (vec == VMAX) hipLaunchKernelGGL((fg_kernel<T, MISSION, WIND, VMAX, PAT>), grid, dim3(TILE), lds, s, a);

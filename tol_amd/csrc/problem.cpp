@@ -202,6 +202,11 @@ void batch::eval(int B, const void *dX, long ldx, void *dF, long ldf, void *dG, 
     // 4.3 TB/s capped, 5.5 TB/s uncapped).
     const double out_bytes = (double)elem_size() * B * ((needF ? sz_.neF : 0) + (needG ? sz_.neG : 0));
     a.waves_per_cu = (waves_forced_ || out_bytes > 192.0 * 1024 * 1024) ? waves_per_cu_ : 0;
+    // a handful of short trajectories (the SNOPT callback is B = 1): one launch, whole trajectory per workgroup
+    static const bool no_single = std::getenv("TOLFG_NO_SINGLE_LAUNCH") != nullptr;
+    // measured per call: ts=100 24.7 vs 29.2 us, ts=200 29.7 vs 33.1 us; at ts=500 (8 waves per workgroup)
+    // the two-launch path is as fast, so the fused form is used up to 4 tiles (ts <= 256)
+    a.single = (!no_single && B <= 8 && args_.tiles <= 4) ? 1 : 0;
     a.X = dX; a.ldx = ldx; a.F = dF; a.ldf = ldf; a.G = dG; a.ldg = ldg;
     a.wind = dWind; a.traj = d_traj_;
     a.B = B; a.needF = needF ? 1 : 0; a.needG = needG ? 1 : 0;

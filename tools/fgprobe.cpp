@@ -67,6 +67,7 @@ int main(int argc, char **argv)
     a.ac[0] = tolfg::AcCoef{1.0 / 6.1228, 1.2682 * 0.6316 / (2 * 6.1228), 0.03, 1.0 / (16.4457 * M_PI * 0.9693)};
     a.stamps = dS; a.variant = variant;
     a.waves_per_cu = argc > 5 ? atoi(argv[5]) : 0;
+    a.single = 0;
 
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
