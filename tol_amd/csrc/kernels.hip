@@ -1,28 +1,33 @@
 // kernels.hip -- hand-written gfx950 (CDNA4) kernels for tol's SNOPT user function.
 //
-// One launch evaluates F and G of a batch of trajectories.  Work decomposition:
+// One evaluation produces F and G of a batch of trajectories.  Work decomposition:
 //
-//   * fg_kernel: one 64-lane wavefront = one workgroup = one TILE; a tile is up to 64 consecutive
-//     collocation nodes of one trajectory, lane = node.  Per node it produces the
-//     defects F[8k+1..8k+8], the contiguous 104-element Jacobian slab, the node's objective-gradient
-//     entries and its objective terms (ref: problem::dynamicConstraints src/problem.cpp:929-1021,
-//     problem::dynamicsGradients src/problem.cpp:1035-1208, wind models 0/1 src/problem.cpp:480-531,
+//   * a TILE is up to 64 consecutive collocation nodes of one trajectory, one wavefront, lane = node
+//     (tile_body).  Per node it produces the defects F[8k+1..8k+8], the node's contiguous Jacobian
+//     slab (104 entries, or 46 in the compact pattern), its objective-gradient entries and its
+//     objective terms (ref: problem::dynamicConstraints src/problem.cpp:929-1021,
+//     problem::dynamicsGradients src/problem.cpp:1035-1208, wind models 0/1/3 src/problem.cpp:480-695,
 //     problemS10::cost/costGradient src/problemS10.cpp:227-386, problemG7::... src/problemG7.cpp:225-384).
-//     One tile per workgroup on purpose: workgroups that walk several tiles (with the next window
-//     prefetched) start in lockstep and stay in phase, and measured 5-10 % slower.
-//   * finalize_kernel: one thread per trajectory adds the tiles' objective partials in tile order
-//     (deterministic, no atomics), handles the last node's objective terms and writes the boundary
-//     rows and their gradients (ref: src/problemS10.cpp:273-305,395-415; src/problemG7.cpp:258-296,
-//     393-513).
+//   * finalize_body: one wavefront per trajectory, lanes = output entries, adds the tiles' objective
+//     terms in tile order (deterministic, no atomics), handles the last node's terms and writes the
+//     boundary rows and their gradients (ref: src/problemS10.cpp:273-305,395-415;
+//     src/problemG7.cpp:258-296,393-513).
+//   * batched path: fg_kernel (one 64-lane workgroup per tile) + finalize_kernel.  One tile per
+//     workgroup on purpose: workgroups that walk several tiles, or several waves that start together,
+//     stay in phase, and measured 5-10 % slower.  The launch requests more LDS than a tile uses to cap
+//     the resident waves per CU at 7-8: the kernel is bound by the HBM write path, which serves
+//     fewer concurrent store streams better.
+//   * callback path (a few short trajectories): fg_single_kernel, whole trajectory per workgroup,
+//     one launch.
 //   * the SNOPT-facing layouts are node-major (x[11k+1+m], G slab c0+104k), so a lane-per-node
 //     access is 88 B / 832 B strided.  The x window is therefore loaded with contiguous 16-byte
 //     loads and transposed through LDS, and the slabs (83 % of all bytes) are written with
-//     contiguous 16-byte stores, 1 KiB per wave instruction.  Of the 104 slab elements only 32 are
-//     computed per node; the 58 structural zeros and the +-1 constants are injected from a
-//     compile-time table while streaming out, so the LDS exchange is 35 elements per node
-//     (17.9 KB per wave in fp64 -> 9 waves per CU).  F (64 B per node) and the objective-gradient
-//     entries (24 B per node) go straight from registers: every lane's piece is contiguous with its
-//     neighbour's, so whole lines are completed by consecutive instructions of the same wave.
+//     contiguous non-temporal 16-byte stores, 1 KiB per wave instruction.  Of the 104 slab elements
+//     only 32 are computed per node; the 58 structural zeros and the +-1 constants are injected from
+//     a compile-time table while streaming out, so the LDS exchange is 35 elements per node
+//     (17.9 KB per wave in fp64).  F (64 B per node) and the objective-gradient entries (24 B per
+//     node) go straight from registers: every lane's piece is contiguous with its neighbour's, so
+//     whole lines are completed inside L2 by consecutive instructions of the same wave.
 //   * air-frame coefficients and per-trajectory constants are wave-uniform: they arrive through
 //     the kernarg segment / scalar loads and live in SGPRs (cheaper than an LDS copy).
 //   * no MFMA: ~1 flop/byte, HBM-bound.
@@ -40,10 +45,10 @@ namespace {
 
 constexpr int TILE = 64;           // nodes per dynamics tile = wavefront width
 #ifndef TOLFG_NO_NT_STORES
-#define TOLFG_NT_STORES 1          // slab stream is non-temporal: +7..11 % on MI355X
+#define TOLFG_NT_STORES 1          // slab stream is non-temporal: +7..19 % on MI355X
 #endif
 #ifndef TOLFG_MIN_WAVES_PER_SIMD
-#define TOLFG_MIN_WAVES_PER_SIMD 2  // register budget 256: the fp64 tile needs ~190 live values
+#define TOLFG_MIN_WAVES_PER_SIMD 2  // register budget; the fp64 tile uses ~100 VGPRs, so this never binds
 #endif
 constexpr int NI = 11;             // variables per node   (problems/*/snopt.param:3)
 constexpr double kGrav = 9.81;     // include/problem.h:72
