@@ -202,6 +202,17 @@ def main():
                 dist.init_process_group("nccl", device_id=torch.device("cuda", local))
             except TypeError:
                 dist.init_process_group("nccl")
+            # first collective here, outside any timing: RCCL builds its rings lazily; if it cannot
+            # (driver / IPC trouble) the run falls back to gloo rather than losing the scaling point
+            try:
+                probe = torch.ones(1, device="cuda")
+                dist.all_reduce(probe)
+                torch.cuda.synchronize()
+            except Exception as exc:      # noqa: BLE001
+                sys.stderr.write(f"bench.py: RCCL collective failed ({exc}); falling back to gloo\n")
+                dist.destroy_process_group()
+                dist.init_process_group("gloo")
+                args.backend = "gloo"
         else:
             dist.init_process_group("gloo")
 
@@ -292,7 +303,8 @@ def main():
                                    f"start offsets (configs[3] recipe); one fused F+G launch + objective gather per step",
                        "mission": args.mission, "aircraft": args.aircraft, "ts": args.ts, "pattern": args.pattern,
                        "batch_per_gpu": B, "global_batch": B * world, "x_buffers": len(dXs),
-                       "parallelism": f"batch-sharded x{world}, RCCL all-gather of objectives" if world > 1 else "single GPU"},
+                       "parallelism": (f"batch-sharded x{world}, " + ("RCCL" if args.backend == "nccl" else "gloo (host-staged)") +
+                                       " all-gather of objectives") if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "tolfg::fg_kernel", "kernel_ms": kern_ms, "kernel_min_ms": kern_min_ms, "algorithmic_bytes_per_launch": alg_bytes,
