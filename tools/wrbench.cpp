@@ -38,6 +38,14 @@ __global__ __launch_bounds__(64) void wr(vec2 *out, int S, int grp, int delay, l
     } else if (MODE == 4) {       // mode 0 with non-temporal stores
         vec2 *base = out + id * S * 64;
         for (int i = 0; i < S; i++) __builtin_nontemporal_store(v, &base[(long)i * 64 + lane]);
+    } else if (MODE == 6) {       // short-stream tile emulation: read 1 KiB, `delay` x 64 dependent fp64 FMAs, S KiB nt stores
+        const vec2 *in = reinterpret_cast<const vec2 *>(out) + (nblocks * (long)S + id) * 64;
+        vec2 r = in[lane];
+        double acc = r.x;
+        for (int d = 0; d < delay * 64; d++) acc = acc * 1.0000001 + r.y;
+        v.x = acc;
+        vec2 *base = out + id * S * 64;
+        for (int i = 0; i < S; i++) __builtin_nontemporal_store(v, &base[(long)i * 64 + lane]);
     } else if (MODE == 5) {       // mode 1 (interleaved groups) with non-temporal stores
         const long g = id / grp, w = id % grp;
         vec2 *base = out + (g * grp * S) * 64;
@@ -62,7 +70,7 @@ int main(int argc, char **argv)
     const long total = 800L << 20;
     const long nblocks = total / (1024L * S);
     vec2 *d;
-    CK(hipMalloc(&d, total + (1 << 20)));
+    CK(hipMalloc(&d, total + total / (S > 0 ? S : 1) + (4 << 20)));   // mode 6 reads 1 KiB per wave from behind the output
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     auto launch = [&]() {
@@ -71,6 +79,7 @@ int main(int argc, char **argv)
         if (mode == 2) hipLaunchKernelGGL(wr<2>, dim3(nblocks), dim3(64), lds, 0, d, S, grp, delay, nblocks);
         if (mode == 3) hipLaunchKernelGGL(wr<3>, dim3(nblocks / 8 * 8), dim3(64), lds, 0, d, S, grp, delay, nblocks / 8 * 8);
         if (mode == 4) hipLaunchKernelGGL(wr<4>, dim3(nblocks), dim3(64), lds, 0, d, S, grp, delay, nblocks);
+        if (mode == 6) hipLaunchKernelGGL(wr<6>, dim3(nblocks), dim3(64), lds, 0, d, S, grp, delay, nblocks);
         if (mode == 5) hipLaunchKernelGGL(wr<5>, dim3(nblocks / grp * grp), dim3(64), lds, 0, d, S, grp, delay, nblocks);
     };
     for (int i = 0; i < 3; i++) launch();
