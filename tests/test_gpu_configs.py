@@ -163,3 +163,43 @@ def test_ragged_batches_and_tile_edges(tolfg, oracle, B, N):
         Fo, Go = ops[t].eval(X[t])
         assert_close(dF[t, :bt.neF].cpu().numpy(), Fo, what=f"ragged F[{t}]")
         assert_close(dG[t, :bt.neG].cpu().numpy(), Go, what=f"ragged G[{t}]")
+
+
+def test_bitwise_reproducible(tolfg, oracle):
+    """No atomics, fixed summation order: two evaluations of the same inputs are bitwise identical."""
+    import torch
+    N, B = 200, 300
+    bt = tolfg.Batch("S10", AIRCRAFT, ts=N)
+    trajs, zis = _batch_inputs(tolfg, oracle, "S10", B, N, 5, n_aircraft=5)
+    bt.set_trajectories(trajs)
+    dX, dF, dG = bt.alloc(B)
+    bt.x0_device(dX)
+    dX[:, 1:bt.n] += 0.01 * torch.randn(B, bt.n - 1, dtype=torch.float64, device="cuda", generator=torch.Generator("cuda").manual_seed(3))
+    outs = []
+    for _ in range(3):
+        dF.zero_(); dG.zero_()
+        bt.eval(dX, dF, dG)
+        torch.cuda.synchronize()
+        outs.append((dF.clone(), dG.clone()))
+    for F, G in outs[1:]:
+        assert torch.equal(F, outs[0][0]) and torch.equal(G, outs[0][1])
+
+
+@pytest.mark.parametrize("mission,B,N", [("S10", 2, 10000), ("G7", 20000, 4), ("S10", 1, 20001)])
+def test_extreme_shapes(tolfg, oracle, mission, B, N):
+    """Very long single trajectories and very many very short ones (odd ts falls back to scalar stores)."""
+    import torch
+    rg = 100.0 if mission == "S10" else 0.0
+    bt = tolfg.Batch(mission, ["tempest"], ts=N)
+    bt.set_trajectories([tolfg.Trajectory(radius_goal=rg, Vref=1.0 + (t % 7)) for t in range(B)])
+    dX, dF, dG = bt.alloc(B)
+    bt.x0_device(dX)
+    dX[:, 1:bt.n] *= 1.001
+    bt.eval(dX, dF, dG)
+    torch.cuda.synchronize()
+    for t in sorted({0, B // 2, B - 1}):
+        o = oracle.Problem(mission, "tempest", N=N, radius_goal=rg, Vref=1.0 + (t % 7))
+        x = dX[t, :bt.n].cpu().numpy()
+        Fo, Go = o.eval(x)
+        assert_close(dF[t, :bt.neF].cpu().numpy(), Fo, what=f"extreme F[{t}]")
+        assert_close(dG[t, :bt.neG].cpu().numpy(), Go, mask=o.undefined_mask(), what=f"extreme G[{t}]")
