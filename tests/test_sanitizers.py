@@ -1,0 +1,77 @@
+"""AddressSanitizer + UBSan over the CPU code: the oracle's C restatement and
+the product's host-side set-up (params.cpp, setup.cpp).  GPU sanitizers are not available on the pool."""
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+SAN = ["-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-fno-omit-frame-pointer", "-g", "-O1"]
+ENV = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+
+
+def test_oracle_under_asan_ubsan(tmp_path):
+    exe = str(tmp_path / "orc_san")
+    subprocess.run(["gcc", "-std=c11", "-D_GNU_SOURCE", *SAN, "-I", os.path.join(ROOT, "oracle"),
+                    os.path.join(HERE, "c", "oracle_sanitize.c"), os.path.join(ROOT, "oracle", "tolfg_oracle.c"),
+                    "-o", exe, "-lm"], check=True)
+    res = subprocess.run([exe], capture_output=True, text=True, env=ENV, timeout=300)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "rc=0" in res.stdout
+
+
+HOST_DRIVER = r'''
+#include <cstdio>
+#include <stdexcept>
+#include <string>
+#include <vector>
+#include "params.h"
+#include "setup.h"
+#include "kernels.h"
+using namespace tolfg;
+int main(int argc, char **argv) {
+    const std::string root = argv[1];
+    int rc = 0;
+    for (const char *m : {"S10", "G7"}) {
+        const int mid = std::string(m) == "S10" ? MISSION_S10 : MISSION_G7;
+        gain g(m, root); limit l(m, root); snopt s(m, root);
+        for (const char *a : {"tempest", "skywalker"}) {
+            aircraft ac(a, root);
+            for (int pat = 0; pat < 2; pat++)
+                for (int N : {1, 5, 64, 201}) {
+                    Sizes sz = make_sizes(mid, N, pat);
+                    std::vector<int> iG(sz.neG), jG(sz.neG);
+                    make_pattern(sz, iG.data(), jG.data());
+                    for (int e = 1; e < sz.neG; e++)
+                        if ((long)iG[e] * sz.n + jG[e] <= (long)iG[e - 1] * sz.n + jG[e - 1]) rc = 1;
+                    std::vector<double> x(sz.n), xl(sz.n), xu(sz.n), Fl(sz.neF), Fu(sz.neF);
+                    initial_guess(sz, ac, Start{1, 2, -3}, 0.7, x.data());
+                    set_limits(sz, ac, l, Start{1, 2, -3}, xl.data(), xu.data(), Fl.data(), Fu.data());
+                    int tiles, nt; plan_tiles(N, 0, &tiles, &nt);
+                    if (tiles * nt < N || nt > 64 || nt % 4) rc = 2;
+                }
+        }
+    }
+    try { aircraft bad("no_such_airframe", root); rc = 3; } catch (const std::length_error &) {}
+    std::printf("host sanitize run rc=%d\n", rc);
+    return rc;
+}
+'''
+
+
+def test_host_setup_under_asan_ubsan(tmp_path):
+    src = tmp_path / "host_san.cpp"
+    src.write_text(HOST_DRIVER)
+    exe = str(tmp_path / "host_san")
+    csrc = os.path.join(ROOT, "tol_amd", "csrc")
+    # plan_tiles lives in kernels.hip (device TU); a two-line host copy keeps this test free of hipcc
+    stub = tmp_path / "plan_tiles.cpp"
+    stub.write_text('#include "kernels.h"\nnamespace tolfg { void plan_tiles(int N, int, int *tiles, int *nt) {'
+                    ' const int t = (N + 63) / 64; int per = (N + t - 1) / t; per = (per + 3) & ~3; if (per > 64) per = 64;'
+                    ' *nt = per; *tiles = (N + per - 1) / per; } }\n')
+    subprocess.run(["g++", "-std=c++17", *SAN, "-I", csrc, "-isystem", "/opt/rocm/include", "-D__HIP_PLATFORM_AMD__",
+                    str(src), str(stub), os.path.join(csrc, "params.cpp"), os.path.join(csrc, "setup.cpp"), "-o", exe],
+                   check=True)
+    data = os.path.join(ROOT, "tol_amd", "data") + "/"
+    res = subprocess.run([exe, data], capture_output=True, text=True, env=ENV, timeout=300)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "rc=0" in res.stdout
