@@ -112,3 +112,31 @@ def test_evaluation_without_a_gpu_fails_loudly(tolfg):
     with pytest.raises(tolfg.TolfgError) as e:
         p.computeF(p.x0())
     assert e.value.code == -3
+
+
+def test_batch_eval_argument_checks_need_no_gpu(tolfg):
+    """Argument errors are reported before anything touches the device."""
+    import ctypes as C
+    L = tolfg.lib()
+    bt = tolfg.Batch("S10", ["tempest"], ts=10)
+    bt.set_trajectories([tolfg.Trajectory() for _ in range(3)])
+    h = bt._h
+    dummy = C.c_void_p(4096)           # never dereferenced: every call below must fail on its arguments
+
+    def rc(B, dX, ldx, dF, ldf, dG, ldg, wind=None, needF=1, needG=1, obj=None):
+        return L.tolfg_batch_eval(h, B, dX, ldx, dF, ldf, dG, ldg, wind, needF, needG, obj, None)
+
+    n, neF, neG = bt.n, bt.neF, bt.neG
+    assert rc(4, dummy, n, dummy, neF, dummy, neG) == -1                   # more trajectories than described
+    assert rc(0, dummy, n, dummy, neF, dummy, neG) == -1
+    assert rc(3, None, n, dummy, neF, dummy, neG) == -1                    # null X
+    assert rc(3, dummy, n - 1, dummy, neF, dummy, neG) == -1               # row stride shorter than the row
+    assert rc(3, dummy, n, dummy, neF, dummy, neG - 1) == -1
+    assert rc(3, dummy, n, None, neF, dummy, neG) == -1                    # F wanted but null
+    assert rc(3, dummy, n, None, neF, dummy, neG, needF=0, obj=dummy) == -1  # objectives need needF
+    assert b"" != L.tolfg_last_error()
+    bt2 = tolfg.Batch("S10", ["tempest"], ts=10, windmodel=99)
+    bt2.set_trajectories([tolfg.Trajectory()])
+    assert L.tolfg_batch_eval(bt2._h, 1, dummy, n, dummy, neF, dummy, neG, None, 1, 1, None, None) == -1   # table wind without a table
+    assert L.tolfg_batch_x0_device(h, 3, None, n, None) == -1
+    assert L.tolfg_write_json(None, None, 0.0, None) == -1
