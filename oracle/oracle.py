@@ -112,7 +112,7 @@ class Problem:
 
     def __init__(self, mission, aircraft="tempest", N=None, east_goal=400.0, north_goal=0.0,
                  radius_goal=100.0, start=(0.0, 0.0, 0.0), windmodel=WIND_SHEAR, Vref=2.4, href=10.0,
-                 wind_table=None, data_root=DATA, gains=None, wind_grid=None):
+                 wind_table=None, data_root=DATA, gains=None, wind_grid=None, ac15=None, lim8=None):
         self.mission = mission
         self.mid = MISSION_ID[mission]
         self.aircraft = aircraft
@@ -130,6 +130,12 @@ class Problem:
             raise ValueError("snopt file must hold 6 values")
         if gains is not None:
             g = np.asarray(gains, dtype=float)
+        if ac15 is not None:      # air-frame / limit values given directly (fixtures with non-shipped coefficients)
+            self.ac15 = np.asarray(ac15, dtype=float).copy()
+            assert self.ac15.shape == (15,)
+        if lim8 is not None:
+            self.lim8 = np.asarray(lim8, dtype=float).copy()
+            assert self.lim8.shape == (8,)
         self.gains = g
         self.N = int(sn[0]) if N is None else int(N)
         self.opt_tol, self.feas_tol = sn[4], sn[5]

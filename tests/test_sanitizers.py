@@ -46,8 +46,10 @@ int main(int argc, char **argv) {
                     std::vector<double> x(sz.n), xl(sz.n), xu(sz.n), Fl(sz.neF), Fu(sz.neF);
                     initial_guess(sz, ac, Start{1, 2, -3}, 0.7, x.data());
                     set_limits(sz, ac, l, Start{1, 2, -3}, xl.data(), xu.data(), Fl.data(), Fu.data());
-                    int tiles, nt; plan_tiles(N, 0, &tiles, &nt);
-                    if (tiles * nt < N || nt > 64 || nt % 4) rc = 2;
+                    for (int cap : {0, 64, 32, 16, 4}) {
+                        int tiles, nt; plan_tiles(N, 0, cap, &tiles, &nt);
+                        if (tiles * nt < N || (tiles - 1) * nt >= N || nt > (cap ? cap : 64) || nt % 4) rc = 2;
+                    }
                 }
         }
     }
@@ -63,13 +65,8 @@ def test_host_setup_under_asan_ubsan(tmp_path):
     src.write_text(HOST_DRIVER)
     exe = str(tmp_path / "host_san")
     csrc = os.path.join(ROOT, "tol_amd", "csrc")
-    # plan_tiles lives in kernels.hip (device TU); a two-line host copy keeps this test free of hipcc
-    stub = tmp_path / "plan_tiles.cpp"
-    stub.write_text('#include "kernels.h"\nnamespace tolfg { void plan_tiles(int N, int, int *tiles, int *nt) {'
-                    ' const int t = (N + 63) / 64; int per = (N + t - 1) / t; per = (per + 3) & ~3; if (per > 64) per = 64;'
-                    ' *nt = per; *tiles = (N + per - 1) / per; } }\n')
     subprocess.run(["g++", "-std=c++17", *SAN, "-I", csrc, "-isystem", "/opt/rocm/include", "-D__HIP_PLATFORM_AMD__",
-                    str(src), str(stub), os.path.join(csrc, "params.cpp"), os.path.join(csrc, "setup.cpp"), "-o", exe],
+                    str(src), os.path.join(csrc, "plan.cpp"), os.path.join(csrc, "params.cpp"), os.path.join(csrc, "setup.cpp"), "-o", exe],
                    check=True)
     data = os.path.join(ROOT, "tol_amd", "data") + "/"
     res = subprocess.run([exe, data], capture_output=True, text=True, env=ENV, timeout=300)

@@ -10,6 +10,7 @@ enum { MISSION_S10 = 0, MISSION_G7 = 1 };
 enum { WIND_NONE = 0, WIND_SHEAR = 1, WIND_TABLE = 2, WIND_GRID = 3 };   // kernel-side enumeration
 enum { MAX_AIRCRAFT = 8 };
 enum { PATTERN_REFERENCE = 0, PATTERN_COMPACT = 1 };   // slab_table.h
+constexpr unsigned kEmptySlotWord = 0xFFFBADADu;        // fused path: every 32-bit word of an empty partial slot
 
 // Air-frame constants as the kernels want them (reciprocals taken once on the host).
 // ref: the members of `aircraft` the path reads, include/parameters.h:25-30, and g/rho,
@@ -62,7 +63,13 @@ struct FgArgs {
     int  pattern;          // PATTERN_REFERENCE (104-entry slabs) | PATTERN_COMPACT (46-entry slabs)
     int  waves_per_cu;     // cap on resident tile waves per CU (0 = whatever fits); host-side launch hint
     int  single;           // 1 = one workgroup per trajectory, one launch (tiles <= 8, small B)
-    double *partial;       // [B*tiles][2] objective partials (sum T^2, sum (r-R)^2), device
+    int  fused;            // 1 = the tile wave that arrives last at its trajectory's counter finalizes (one launch);
+                           // 0 = finalize_kernel follows fg_kernel
+    int  nt_stores;        // 1 = the slab stream carries the non-temporal hint (outputs beyond the Infinity Cache)
+    int  xcd_chunk;        // > 0: ceil(B*tiles/8), workgroup id -> tile (id % 8) * xcd_chunk + id / 8; 0: id -> tile id
+    double *partial;       // [B*tiles][2] objective partials (sum T^2, sum (r-R)^2), device; on the fused path
+                           // every slot is "empty" (kEmptySlotWord) between launches
+    unsigned *counter;     // [B] arrival counters of the fused path: zero before a launch, reset by the finalizing wave
     void   *obj;           // optional [B]: finalize_kernel also writes the objectives here, contiguous
     double kT, kp, kv, kdt;
     AcCoef ac[MAX_AIRCRAFT];
@@ -74,8 +81,11 @@ struct FgArgs {
 #endif
 };
 
-// Tiling of one trajectory's N dynamic nodes: `tiles` tiles of `nt` nodes (the last may be short).
-void plan_tiles(int N, int dtype, int *tiles, int *nt);
+// Tiling of one trajectory's N dynamic nodes: `tiles` tiles of `nt` <= max_nt nodes (the last may be
+// short).  max_nt is a multiple of 4 in [4, 64]; 0 = 64.
+void plan_tiles(int N, int dtype, int max_nt, int *tiles, int *nt);
+// Tile size the host picks for a launch of B trajectories of N nodes (measured)
+int pick_tile_nodes(int B, int N, int dtype, int pattern);
 
 // One evaluation = fg_kernel + finalize_kernel on stream s: F and G of B trajectories.  dtype: 0 = f64, 1 = f32.  vec = elements per
 // 16-byte access the caller has verified alignment for (f64: 2 or 1; f32: 4 or 1).

@@ -44,9 +44,6 @@ namespace tolfg {
 namespace {
 
 constexpr int TILE = 64;           // nodes per dynamics tile = wavefront width
-#ifndef TOLFG_NO_NT_STORES
-#define TOLFG_NT_STORES 1          // slab stream is non-temporal: +7..19 % on MI355X
-#endif
 #ifndef TOLFG_MIN_WAVES_PER_SIMD
 #define TOLFG_MIN_WAVES_PER_SIMD 2  // register budget; the fp64 tile uses ~100 VGPRs, so this never binds
 #endif
@@ -56,6 +53,9 @@ constexpr double kTwoPi = 6.283185307179586476925286766559;
 
 // LDS row of one node (elements): 32 computed Jacobian values and the 3 constants (slab_table.h).
 constexpr int RS = 35;             // odd stride: conflict-free ds_write_b64 across lanes
+// an empty objective-partial slot of the polling fused path: a NaN no arithmetic produces, both halves
+// equal so that hipMemsetD32 can write it
+constexpr unsigned long long kEmptySlot = 0xFFFBADADFFFBADADull;
 
 __device__ constexpr SlabTableFull kSlabFull = make_slab_table();
 __device__ constexpr SlabTableCompact kSlabCompact = make_compact_table();
@@ -94,7 +94,7 @@ __device__ __forceinline__ float sqrt_t(float a) { return sqrtf(a); }
 
 // Output is written once and never read back by the GPU: with TOLFG_NT_STORES the streaming stores
 // carry the non-temporal hint so that they do not displace the x rows from L2 / Infinity Cache.
-template <typename V>
+template <bool NT, typename V>
 __device__ __forceinline__ void stream_store(V *p, V v)
 {
 #if defined(TOLFG_STORE_FLAVOR)
@@ -106,10 +106,9 @@ __device__ __forceinline__ void stream_store(V *p, V v)
     } else {
         *p = v;
     }
-#elif defined(TOLFG_NT_STORES)
-    __builtin_nontemporal_store(v, p);
 #else
-    *p = v;
+    if constexpr (NT) __builtin_nontemporal_store(v, p);
+    else *p = v;
 #endif
 }
 
@@ -309,7 +308,7 @@ template <typename T, int PAT, int GV> struct SlabOffsets {
     }
 };
 
-template <typename T, int PAT, int GV>
+template <typename T, int PAT, int GV, bool NT>
 __device__ __forceinline__ void store_slabs(const T *lds, T *gslab, int cnt, int lane, const SlabOffsets<T, PAT, GV> &so)
 {
     typedef typename Vec<T, GV>::type vec;
@@ -324,12 +323,12 @@ __device__ __forceinline__ void store_slabs(const T *lds, T *gslab, int cnt, int
             const int p = TILE * (Gm::P * j + t) + lane;
             if (p < total) {
                 if constexpr (GV == 1) {
-                    stream_store(gslab + p, grp[so.off(t, 0)]);
+                    stream_store<NT>(gslab + p, grp[so.off(t, 0)]);
                 } else {
                     vec val;
 #pragma unroll
                     for (int v = 0; v < GV; v++) val[v] = grp[so.off(t, v)];
-                    stream_store(reinterpret_cast<vec *>(gslab + (long)p * GV), val);
+                    stream_store<NT>(reinterpret_cast<vec *>(gslab + (long)p * GV), val);
                 }
             }
         }
@@ -361,10 +360,31 @@ __device__ __forceinline__ void store_defects(T *p, const T (&d)[8])
     }
 }
 
+// Fused path: how a tile wave hands its objective terms to whichever wave finalizes the trajectory.
+// Nobody waits: the payload leaves as write-through (sc1) stores into this tile's own slot, then one
+// agent-scope atomic add on the trajectory's arrival counter, whose returned value is looked at only
+// when the wave has issued all its stores.  The wave whose add returned tiles-1 finalizes: it polls
+// the slots (sc1 loads) until none is empty -- every tile stored its payload before it arrived, so
+// that is at most one store round trip -- and empties them again for the next launch.
+struct Publish {
+    double *slot;          // this tile's [2] partial slot, or nullptr (not fused)
+    unsigned *counter;     // the trajectory's arrival counter
+    unsigned old;          // value the add returned (lane 0)
+    __device__ __forceinline__ void arrive(int lane, bool needF, double sumT, double sumP)
+    {
+        if (!slot || lane != 0) return;
+        if (needF) {
+            __hip_atomic_store(slot + 0, sumT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(slot + 1, sumP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        old = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+};
+
 // One tile: everything a wavefront does for `cnt` consecutive nodes of trajectory b.  lds is the
 // wave's own TILE*RS-element region; sumT / sumP return the tile's objective terms (wave-uniform).
-template <typename T, int MISSION, int WIND, int VEC, int PAT>
-__device__ __forceinline__ void tile_body(const FgArgs &a, T *lds, int item, int lane, T &sumT_out, T &sumP_out)
+template <typename T, int MISSION, int WIND, int VEC, int PAT, bool NT>
+__device__ __forceinline__ void tile_body(const FgArgs &a, T *lds, int item, int lane, T &sumT_out, T &sumP_out, Publish &pub)
 {
     typedef typename Vec<T, VEC>::type vec;
     // slab stores: 16 bytes per lane where the slab length allows (46 floats are 23 pairs, not quads)
@@ -444,7 +464,7 @@ __device__ __forceinline__ void tile_body(const FgArgs &a, T *lds, int item, int
         store_defects<T, VEC>(Frow + 1 + 8 * (k0 + lane), d8);
     }
 
-    // ---- objective terms of this tile's nodes (node N is finalize_kernel's)
+    // ---- objective terms of this tile's nodes (node N is the finalizing wave's)
     const T kT = T(a.kT), kp = T(a.kp);
     T sumT = act ? s[10] * s[10] : T(0), sumP = T(0);
     if constexpr (MISSION == MISSION_S10) {
@@ -469,6 +489,7 @@ __device__ __forceinline__ void tile_body(const FgArgs &a, T *lds, int item, int
     }
     sumT_out = sumT;
     sumP_out = sumP;
+    pub.arrive(lane, a.needF != 0, (double)sumT, (double)sumP);
 
     if (a.needG) {
         T *row = lds + lane * RS;
@@ -485,7 +506,7 @@ __device__ __forceinline__ void tile_body(const FgArgs &a, T *lds, int item, int
         __builtin_amdgcn_sched_barrier(0);
         SlabOffsets<T, PAT, GV> so;
         so.init(lane);
-        if (!(TOLFG_VARIANT(a) & 2048)) store_slabs<T, PAT, GV>(lds, Grow + a.c0 + (long)SLABN * k0, cnt, lane, so);
+        if (!(TOLFG_VARIANT(a) & 2048)) store_slabs<T, PAT, GV, NT>(lds, Grow + a.c0 + (long)SLABN * k0, cnt, lane, so);
         TOLFG_STAMP(a, 4);
     }
     TOLFG_STAMP(a, 5);
@@ -494,23 +515,6 @@ __device__ __forceinline__ void tile_body(const FgArgs &a, T *lds, int item, int
     TOLFG_STAMP(a, 6);
     TOLFG_REALTIME(a, 8);
 #endif
-}
-
-// fg_kernel: one 64-lane workgroup per tile; consecutive workgroups walk the batch's memory in order.
-template <typename T, int MISSION, int WIND, int VEC, int PAT>
-__global__ __launch_bounds__(TILE, TOLFG_MIN_WAVES_PER_SIMD) void fg_kernel(const FgArgs a)
-{
-    // dynamic LDS: TILE*RS elements are used; the launch may request more to cap the waves per CU
-    // (fewer concurrent store streams suit the HBM write path better, DESIGN.md section 6)
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    const int lane = threadIdx.x;
-    const int item = blockIdx.x;
-    T sumT, sumP;
-    tile_body<T, MISSION, WIND, VEC, PAT>(a, reinterpret_cast<T *>(lds_raw), item, lane, sumT, sumP);
-    if (a.needF && lane == 0) {
-        a.partial[2 * (long)item + 0] = (double)sumT;
-        a.partial[2 * (long)item + 1] = (double)sumP;
-    }
 }
 
 // One wavefront per trajectory, lanes = output entries: objective value, the last node's
@@ -633,18 +637,86 @@ __device__ __forceinline__ void finalize_body(const FgArgs &a, int b, int lane, 
     }
 }
 
+// Sum of a trajectory's tile partials in one fixed order (lane l adds tiles l, l+64, ...; then the
+// butterfly), so the objective does not depend on which wave finalizes or on arrival order.
+// POLL false: plain loads (an earlier launch or this workgroup's LDS wrote them); true: waves of this
+// launch on other XCDs wrote them -- sc1 loads that poll until the slot is no longer empty, then
+// empty it again for the next launch.
+template <typename T, bool POLL>
+__device__ __forceinline__ void sum_partials(const double *part, int tiles, int lane, T &sumT, T &sumP)
+{
+    T st = T(0), sp = T(0);
+    for (int t = lane; t < tiles; t += TILE) {
+        if constexpr (POLL) {
+            unsigned long long *q = reinterpret_cast<unsigned long long *>(const_cast<double *>(part)) + 2 * t;
+            unsigned long long b0, b1;
+            // every tile wave stores its payload before it arrives, so the slots fill within a store
+            // round trip; the spin bound only guards against an input that carries the marker itself
+            for (int spin = 0; spin < (1 << 20); spin++) {
+                b0 = __hip_atomic_load(q + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                b1 = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (b0 != kEmptySlot && b1 != kEmptySlot) break;
+                __builtin_amdgcn_s_sleep(8);
+            }
+            __hip_atomic_store(q + 0, kEmptySlot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(q + 1, kEmptySlot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            st += T(__builtin_bit_cast(double, b0));
+            sp += T(__builtin_bit_cast(double, b1));
+        } else {
+            st += T(part[2 * t + 0]);
+            sp += T(part[2 * t + 1]);
+        }
+    }
+    sumT = wave_sum(st);
+    sumP = wave_sum(sp);
+}
+
+// fg_kernel: one 64-lane workgroup per tile.  Workgroup ids go round-robin over the 8 XCDs; with
+// a.xcd_chunk > 0 workgroup id works on tile (id % 8) * xcd_chunk + id / 8, so that every XCD walks
+// its own contiguous eighth of the batch's memory (measured +6 % on the write stream,
+// profiles/r02_write_shapes.md); otherwise consecutive workgroups walk the memory in order.
+// Fused form (a.fused): the wave that arrives last at its trajectory's counter also finalizes it, so
+// an evaluation is one launch; otherwise finalize_kernel follows.
+template <typename T, int MISSION, int WIND, int VEC, int PAT, bool NT>
+__global__ __launch_bounds__(TILE, TOLFG_MIN_WAVES_PER_SIMD) void fg_kernel(const FgArgs a)
+{
+    // dynamic LDS: TILE*RS elements are used; the launch may request more to cap the waves per CU
+    // (fewer concurrent store streams suit the HBM write path better, DESIGN.md section 6)
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const int lane = threadIdx.x;
+    int item = blockIdx.x;
+    if (a.xcd_chunk > 0) {
+        item = (item & 7) * a.xcd_chunk + (item >> 3);
+        if (item >= a.B * a.tiles) return;         // the grid is rounded up to 8 * xcd_chunk
+    }
+    const int b = item / a.tiles;
+    T sumT, sumP;
+    Publish pub{nullptr, nullptr, 0u};
+    if (a.fused) {
+        pub.slot = a.partial + 2 * (long)item;
+        pub.counter = a.counter + b;
+    }
+    tile_body<T, MISSION, WIND, VEC, PAT, NT>(a, reinterpret_cast<T *>(lds_raw), item, lane, sumT, sumP, pub);
+    if (a.fused) {
+        const unsigned old = __builtin_amdgcn_readfirstlane(pub.old);
+        if (old == (unsigned)(a.tiles - 1)) {          // wave-uniform: every tile of b has arrived
+            if (lane == 0) __hip_atomic_store(pub.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            T st = T(0), sp = T(0);
+            if (a.needF) sum_partials<T, true>(a.partial + 2 * (long)b * a.tiles, a.tiles, lane, st, sp);
+            finalize_body<T, MISSION, PAT>(a, b, lane, st, sp);
+        }
+    } else if (a.needF && lane == 0) {
+        a.partial[2 * (long)item + 0] = (double)sumT;
+        a.partial[2 * (long)item + 1] = (double)sumP;
+    }
+}
+
 template <typename T, int MISSION, int PAT>
 __global__ __launch_bounds__(TILE) void finalize_kernel(const FgArgs a)
 {
     const int b = blockIdx.x;
     T sumT = T(0), sumP = T(0);
-    if (a.needF) {
-        const double *part = a.partial + 2 * (long)b * a.tiles;
-        for (int t = 0; t < a.tiles; t++) {
-            sumT += T(part[2 * t + 0]);
-            sumP += T(part[2 * t + 1]);
-        }
-    }
+    if (a.needF) sum_partials<T, false>(a.partial + 2 * (long)b * a.tiles, a.tiles, threadIdx.x, sumT, sumP);
     finalize_body<T, MISSION, PAT>(a, b, threadIdx.x, sumT, sumP);
 }
 
@@ -661,13 +733,13 @@ __global__ __launch_bounds__(8 * TILE) void fg_single_kernel(const FgArgs a)
     const int b = blockIdx.x;
     double *red = reinterpret_cast<double *>(lds + (long)a.tiles * TILE * RS);     // [tiles][2]
     T sumT, sumP;
-    tile_body<T, MISSION, WIND, VEC, PAT>(a, lds + (long)w * TILE * RS, b * a.tiles + w, lane, sumT, sumP);
+    Publish pub{nullptr, nullptr, 0u};
+    tile_body<T, MISSION, WIND, VEC, PAT, false>(a, lds + (long)w * TILE * RS, b * a.tiles + w, lane, sumT, sumP, pub);
     if (lane == 0) { red[2 * w] = (double)sumT; red[2 * w + 1] = (double)sumP; }
     __syncthreads();
     if (w == 0) {
         T st = T(0), sp = T(0);
-        if (a.needF)
-            for (int t = 0; t < a.tiles; t++) { st += T(red[2 * t]); sp += T(red[2 * t + 1]); }
+        if (a.needF) sum_partials<T, false>(red, a.tiles, lane, st, sp);
         finalize_body<T, MISSION, PAT>(a, b, lane, st, sp);
     }
 }
@@ -703,13 +775,20 @@ hipError_t launch_vec(const FgArgs &a, int vec, dim3 grid, hipStream_t s, hipEve
     }
     if (t0 && (e = hipEventRecord(t0, s)) != hipSuccess) return e;
     const unsigned lds = (unsigned)fg_lds_request(sizeof(T) == 8 ? 0 : 1, a.waves_per_cu);
-    if (vec == VMAX) hipLaunchKernelGGL((fg_kernel<T, MISSION, WIND, VMAX, PAT>), grid, dim3(TILE), lds, s, a);
-    else             hipLaunchKernelGGL((fg_kernel<T, MISSION, WIND, 1, PAT>), grid, dim3(TILE), lds, s, a);
+    if (vec == VMAX) {
+        if (a.nt_stores) hipLaunchKernelGGL((fg_kernel<T, MISSION, WIND, VMAX, PAT, true>), grid, dim3(TILE), lds, s, a);
+        else             hipLaunchKernelGGL((fg_kernel<T, MISSION, WIND, VMAX, PAT, false>), grid, dim3(TILE), lds, s, a);
+    } else {
+        hipLaunchKernelGGL((fg_kernel<T, MISSION, WIND, 1, PAT, false>), grid, dim3(TILE), lds, s, a);
+    }
     e = hipGetLastError();
     if (e != hipSuccess) return e;
-    if (t1 && (e = hipEventRecord(t1, s)) != hipSuccess) return e;
-    hipLaunchKernelGGL((finalize_kernel<T, MISSION, PAT>), dim3(a.B), dim3(TILE), 0, s, a);
-    return hipGetLastError();
+    if (!a.fused) {
+        hipLaunchKernelGGL((finalize_kernel<T, MISSION, PAT>), dim3(a.B), dim3(TILE), 0, s, a);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+    }
+    // the events bracket the whole evaluation: fg_kernel, and finalize_kernel when it is a launch of its own
+    return t1 ? hipEventRecord(t1, s) : hipSuccess;
 }
 
 template <typename T, int MISSION, int PAT>
@@ -854,29 +933,18 @@ __global__ void bounds_kernel(const BoundsArgs a)
 
 }  // namespace
 
-void plan_tiles(int N, int dtype, int *tiles, int *nt)
-{
-    // ceil(N/64) tiles of equal size, the size rounded up to 4 nodes so that every tile's x window
-    // (11*k0 elements into the row) starts on a 16-byte boundary for both element sizes
-    (void)dtype;
-    const int t = (N + TILE - 1) / TILE;
-    int per = (N + t - 1) / t;
-    per = (per + 3) & ~3;
-    if (per > TILE) per = TILE;
-    *nt = per;
-    *tiles = (N + per - 1) / per;
-}
-
 hipError_t launch_fg(const FgArgs &a, int mission, int wind, int dtype, int vec, hipStream_t s, hipEvent_t t0,
                      hipEvent_t t1)
 {
     if (a.B <= 0) return hipSuccess;
-    int tiles, nt;
-    plan_tiles(a.N, dtype, &tiles, &nt);
-    if (a.N < 1 || a.tiles != tiles || a.nt != nt || !a.partial) return hipErrorInvalidValue;
+    // the tiling must be one plan_tiles() can produce: nt a multiple of 4 in [4, 64], tiles = ceil(N/nt)
+    if (a.N < 1 || a.nt < 4 || a.nt > TILE || (a.nt & 3) || a.tiles != (a.N + a.nt - 1) / a.nt || !a.partial)
+        return hipErrorInvalidValue;
+    if (a.fused && !a.single && !a.counter) return hipErrorInvalidValue;
     const long W = (long)a.B * a.tiles;
-    if (W > 0x7fffffffL) return hipErrorInvalidValue;
-    const dim3 grid((unsigned)W);
+    if (W > 0x7ffffff0L) return hipErrorInvalidValue;
+    if (a.xcd_chunk != 0 && a.xcd_chunk != (int)((W + 7) / 8)) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)(a.xcd_chunk > 0 ? 8L * a.xcd_chunk : W));
     if (a.pattern == PATTERN_COMPACT) {
         return dtype == 0 ? launch_mission<double, PATTERN_COMPACT>(a, mission, wind, vec, grid, s, t0, t1)
                           : launch_mission<float, PATTERN_COMPACT>(a, mission, wind, vec, grid, s, t0, t1);

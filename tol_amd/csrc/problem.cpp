@@ -92,7 +92,11 @@ batch::batch(const std::string &mission, const std::string &root, const std::vec
     waves_per_cu_ = (dtype == TOLFG_F64 && pattern == PATTERN_REFERENCE) ? 7 : 8;
     if (const char *e = std::getenv("TOLFG_WAVES_PER_CU")) { waves_per_cu_ = std::atoi(e); waves_forced_ = true; }
     args_.N = N;
-    plan_tiles(N, dtype, &args_.tiles, &args_.nt);
+    plan_tiles(N, dtype, 0, &args_.tiles, &args_.nt);      // eval() re-plans for its batch size
+    if (const char *e = std::getenv("TOLFG_TILE_NODES")) tile_nodes_forced_ = std::atoi(e);
+    if (const char *e = std::getenv("TOLFG_FUSED")) fused_ = std::atoi(e) != 0;
+    if (const char *e = std::getenv("TOLFG_NT_STORES")) nt_forced_ = std::atoi(e) != 0;
+    if (const char *e = std::getenv("TOLFG_XCD")) xcd_ = std::atoi(e) != 0;
     args_.c0 = sz_.c0;
     args_.kT = gn_.kT; args_.kp = gn_.kp; args_.kv = gn_.kv; args_.kdt = gn_.kdt;
     for (size_t i = 0; i < acs_.size(); ++i) {
@@ -109,6 +113,7 @@ batch::~batch()
 {
     if (d_traj_) (void)hipFree(d_traj_);
     if (d_partial_) (void)hipFree(d_partial_);
+    if (d_counter_) (void)hipFree(d_counter_);
     if (d_grid_) (void)hipFree(d_grid_);
     for (hipEvent_t e : ev_) if (e) (void)hipEventDestroy(e);
 }
@@ -186,27 +191,44 @@ void batch::eval(int B, const void *dX, long ldx, void *dF, long ldf, void *dG, 
     if (windmodel_ == TOLFG_WIND_TABLE && !dWind) throw std::invalid_argument("eval: table wind needs dWind");
     if (windmodel_ == TOLFG_WIND_GRID && !d_grid_) throw std::invalid_argument("eval: grid wind needs tolfg_*_set_wind_grid");
     if (!uploaded_) upload();
-    const long W = (long)B * args_.tiles;
+    FgArgs a = args_;
+    // a handful of short trajectories (the SNOPT callback is B = 1): one launch, whole trajectory per
+    // workgroup (measured per call: ts=100 24.7 vs 29.2 us, ts=200 29.7 vs 33.1 us; at ts=500, 8 waves
+    // per workgroup, the tile-per-workgroup path is as fast, so the single form is used up to ts = 256)
+    static const bool no_single = std::getenv("TOLFG_NO_SINGLE_LAUNCH") != nullptr;
+    a.single = (!no_single && B <= 8 && a.N <= 256) ? 1 : 0;
+    plan_tiles(a.N, dtype_, a.single ? 0 : (tile_nodes_forced_ > 0 ? tile_nodes_forced_ : pick_tile_nodes(B, a.N, dtype_, a.pattern)),
+               &a.tiles, &a.nt);
+    const long W = (long)B * a.tiles;
     if (W > partial_cap_) {        // objective partials, 2 doubles per tile
         check(hipSetDevice(device_), "hipSetDevice");
         if (d_partial_) check(hipFree(d_partial_), "hipFree");
         d_partial_ = nullptr;
         check(hipMalloc(reinterpret_cast<void **>(&d_partial_), sizeof(double) * 2 * (size_t)W), "hipMalloc(partial)");
+        // fused path: every slot starts empty and is emptied again by the wave that read it
+        check(hipMemsetD32(reinterpret_cast<hipDeviceptr_t>(d_partial_), kEmptySlotWord, 4 * (size_t)W), "hipMemsetD32(partial)");
         partial_cap_ = W;
     }
-    FgArgs a = args_;
+    if (B > counter_cap_) {        // arrival counters of the fused path: zero between launches
+        check(hipSetDevice(device_), "hipSetDevice");
+        if (d_counter_) check(hipFree(d_counter_), "hipFree");
+        d_counter_ = nullptr;
+        check(hipMalloc(reinterpret_cast<void **>(&d_counter_), sizeof(unsigned) * (size_t)B), "hipMalloc(counter)");
+        check(hipMemset(d_counter_, 0, sizeof(unsigned) * (size_t)B), "hipMemset(counter)");
+        counter_cap_ = B;
+    }
     a.partial = d_partial_;
+    a.counter = d_counter_;
+    a.fused = fused_ ? 1 : 0;
     a.obj = dObj;
     // The cap pays only when the output stream really goes to HBM; a batch whose F and G fit the
     // 256 MiB Infinity Cache is served on-die and wants every wave it can get (B = 1024, ts = 200:
     // 4.3 TB/s capped, 5.5 TB/s uncapped).
     const double out_bytes = (double)elem_size() * B * ((needF ? sz_.neF : 0) + (needG ? sz_.neG : 0));
-    a.waves_per_cu = (waves_forced_ || out_bytes > 192.0 * 1024 * 1024) ? waves_per_cu_ : 0;
-    // a handful of short trajectories (the SNOPT callback is B = 1): one launch, whole trajectory per workgroup
-    static const bool no_single = std::getenv("TOLFG_NO_SINGLE_LAUNCH") != nullptr;
-    // measured per call: ts=100 24.7 vs 29.2 us, ts=200 29.7 vs 33.1 us; at ts=500 (8 waves per workgroup)
-    // the two-launch path is as fast, so the fused form is used up to 4 tiles (ts <= 256)
-    a.single = (!no_single && B <= 8 && args_.tiles <= 4) ? 1 : 0;
+    const bool beyond_cache = out_bytes > 192.0 * 1024 * 1024;
+    a.waves_per_cu = (waves_forced_ || beyond_cache) ? waves_per_cu_ : 0;
+    a.nt_stores = nt_forced_ >= 0 ? nt_forced_ : (beyond_cache ? 1 : 0);
+    a.xcd_chunk = (xcd_ && !a.single) ? (int)((W + 7) / 8) : 0;
     a.X = dX; a.ldx = ldx; a.F = dF; a.ldf = ldf; a.G = dG; a.ldg = ldg;
     a.wind = dWind; a.traj = d_traj_;
     a.B = B; a.needF = needF ? 1 : 0; a.needG = needG ? 1 : 0;
@@ -217,7 +239,7 @@ void batch::eval(int B, const void *dX, long ldx, void *dF, long ldf, void *dG, 
                          (!needG || ((reinterpret_cast<uintptr_t>(dG) % 16 == 0) && (ldg % vmax == 0) &&
                                      (sz_.c0 % vmax == 0)));
     hipEvent_t t0 = nullptr, t1 = nullptr;
-    if (timing_) {                 // HIP events on the launch stream, around fg_kernel only
+    if (timing_) {                 // HIP events on the launch stream, around the whole evaluation
         if (ev_used_ + 2 > ev_.size()) {
             const size_t old = ev_.size();
             ev_.resize(old + 64, nullptr);

@@ -77,6 +77,12 @@ private:
     void *d_grid_ = nullptr;
     double *d_partial_ = nullptr;
     long partial_cap_ = 0;
+    unsigned *d_counter_ = nullptr;
+    int counter_cap_ = 0;
+    int tile_nodes_forced_ = 0;         // TOLFG_TILE_NODES (measurements)
+    bool fused_ = true;                 // TOLFG_FUSED=0 selects fg_kernel + finalize_kernel (measurements)
+    int nt_forced_ = -1;                // TOLFG_NT_STORES=0/1 overrides the size-based choice (measurements)
+    bool xcd_ = true;                   // TOLFG_XCD=0: workgroup id -> tile id (measurements)
     int ntraj_ = 0, cap_ = 0;
     bool uploaded_ = false;
     TrajDev *d_traj_ = nullptr;

@@ -8,6 +8,7 @@
 //
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DTOLFG_STAMPS -o gpurun_out/fgprobe tools/fgprobe.cpp
 #include "../tol_amd/csrc/kernels.hip"
+#include "../tol_amd/csrc/plan.cpp"
 
 #include <algorithm>
 #include <cmath>
@@ -45,7 +46,7 @@ int main(int argc, char **argv)
 
     double *dX, *dF, *dG; tolfg::TrajDev *dT; unsigned long long *dS;
     int tiles, nt;
-    tolfg::plan_tiles(N, 0, &tiles, &nt);
+    tolfg::plan_tiles(N, 0, 0, &tiles, &nt);
     const int ipb = (variant & 255) > 0 ? (variant & 255) : 1;
     const long W = (long)B * tiles;
     const long blocks = W; (void)ipb;

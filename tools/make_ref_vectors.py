@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""BUILD-CONTAINER TOOL: reference-derived golden vectors for the user-function path.
+
+Reads the reference's sources under /root/reference at RUN TIME (they are never copied), evaluates the
+functions on the path with tools/refeval/cinterp.py -- a small interpreter for the C++ subset they are
+written in -- and stores only NUMBERS (inputs and the outputs the reference's own code produced) in
+tests/golden/ref_eval_vectors.npz.  Only that .npz travels to the GPU box.
+
+What is evaluated, per case, exactly in the reference's own calling order
+(src/problemS10.cpp:9-17 / src/problemG7.cpp:9-17 constructors, src/DefineFG.cpp:9-48):
+    InitialCond()  -> x0            setLimits() -> xlow, xupp, Flow, Fupp       countG(x0) -> pattern
+    for every test point x:   modelWind(x);  computeF(x, F);  computeG(x, G)
+with wind model 1 (the offline fallback), model 99 (a seeded per-node ENU wind table left untouched
+by modelWind's `default:` arm, SURVEY.md section 8c "wind injection") and model 3 (trilinear grid,
+a synthetic cache), non-shipped gains (kT, kp, kv, kdt all different and non-zero), perturbed
+air-frame coefficients and seeded decision vectors.  The object state a constructor would have set
+(src/problem.cpp:13-192) is supplied as data below, each member with the line it mirrors.
+
+The interpreter reads a scalar declared without an initialiser as NaN, so the reference's 11
+undefined S10 entries (src/problemS10.cpp:397) come out as NaN in G; the fixture keeps them as NaN and
+the tests mask them.
+
+usage: python tools/make_ref_vectors.py            (writes tests/golden/ref_eval_vectors.npz)
+"""
+import math
+import os
+import sys
+import time
+from types import SimpleNamespace as NS
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "refeval"))
+import cinterp  # noqa: E402
+
+REF = "/root/reference"
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden", "ref_eval_vectors.npz")
+
+
+def read_param_values(path):
+    """Numbers of a .param file (text before the first '/', leading float) -- plain data input."""
+    vals = []
+    with open(path, errors="replace") as fh:
+        for line in fh:
+            head = line.split("/")[0].strip()
+            try:
+                vals.append(float(head.split("\\")[0]))
+            except ValueError:
+                continue
+    return vals
+
+
+def aircraft_members(v):
+    """aircraft::aircraft, src/parameters.cpp:42-67: 15 values, three of them degrees."""
+    return NS(mm=v[0], b=v[1], SS=v[2], ee=v[3], AR=v[4], Cd0=v[5], CLmin=v[6], CLmax=v[7], phimax=v[8] * math.pi / 180.0,
+              Vamin=v[9], Vamax=v[10], gammamax=v[11] * math.pi / 180.0, phidotmax=v[12] * math.pi / 180.0, Tmin=v[13], Tmax=v[14])
+
+
+class RefProblem:
+    """The members a constructed problemS10 / problemG7 holds (src/problem.cpp:13-192), as data."""
+
+    def __init__(self, mission, N, ac, gains, lim, goal, start):
+        self._classes = ["problem" + mission, "problem"]
+        nb = 11 if mission == "S10" else 12
+        self.sn = NS(ts=int(N), numinp=11, numstates=8, numbounds=nb, opt_tol=1e-6, feas_tol=1e-6)
+        self.ac = ac
+        self.gn = NS(kT=gains[0], kp=gains[1], kv=gains[2], ka=gains[3], kdt=gains[4])
+        # limit::limit, src/parameters.cpp:107-114
+        self.lm = NS(dtmin=lim[0], dtmax=lim[1], xmin=lim[2], xmax=lim[3], ymin=lim[4], ymax=lim[5], zmin=lim[6], zmax=lim[7])
+        self.g, self.rho, self.pi = 9.81, 1.2682, math.pi                      # include/problem.h:72-74
+        east_goal, north_goal, up_goal, radius = goal
+        self.yg, self.xg, self.zg, self.rg = float(east_goal), float(north_goal), -float(up_goal), float(radius)   # :24-27
+        self.mission = mission
+        self.xi, self.yi, self.zi = (float(s) for s in start)                  # :83-85 / :111-113 (0 in the reference)
+        if mission == "S10":                                                    # :80-106
+            self.Va1, self.Va2, self.gamma1, self.gamma2 = 4.0, 50.0, 0.0, 0.0
+            self.chi1, self.chi2 = -1.7453292519943296e+18, 1.7453292519943296e+18
+            self.phi1, self.phi2 = -1.5707963267948966, 1.5707963267948966
+        else:                                                                   # :108-134
+            self.Va1, self.Va2 = 4.0, 50.0
+            self.gamma1, self.gamma2 = 0.0 * math.pi / 180.0, 0.0 * math.pi / 180.0
+            self.chi1, self.chi2 = -1e20 * math.pi / 180.0, 1e20 * math.pi / 180.0
+            self.phi1, self.phi2 = -90.0 * math.pi / 180.0, 90.0 * math.pi / 180.0
+        self.CL1, self.CL2 = -0.5, 3.0
+        self.phidot1, self.phidot2 = -3.4906585039886591, 3.4906585039886591
+        self.CLdot1, self.CLdot2 = -200.0, 200.0
+        self.chi_d = 0.0                                                        # set by RotateYaw (G7)
+        T = N + 1
+        for name in ("u", "v", "w", "du_dx", "du_dy", "du_dz", "dv_dx", "dv_dy", "dv_dz", "dw_dx", "dw_dy", "dw_dz"):
+            setattr(self, name, [0.0] * T)                                      # :137-148
+        self.n = 11 * (N + 1) + 1                                               # :151
+        self.neF = 8 * N + 1 + nb                                               # :152
+        lenG = self.neF * self.n                                                # :159
+        self.lenG = lenG
+        self.iGfun, self.jGvar = [0] * lenG, [0] * lenG
+        self.x, self.xlow, self.xupp = [0.0] * self.n, [0.0] * self.n, [0.0] * self.n
+        self.xmul, self.xstate = [0.0] * self.n, [0] * self.n
+        self.F, self.Flow, self.Fupp = [0.0] * self.neF, [0.0] * self.neF, [0.0] * self.neF
+        self.Fmul, self.Fstate = [0.0] * self.neF, [0] * self.neF
+        self.neG, self.neA = 0, 0                                               # :181-182
+        self.F_sparse, self.x_sparse = [0.0] * lenG, [0.0] * lenG               # :185-188 (vectors of double)
+        self.tf_sparse, self.tx_sparse = [0.0] * lenG, [0.0] * lenG
+        self.Gnonzero = 0
+        self.Pwindmodel = 1                                                     # offline fallback, :73-78
+        for name in ("Wx", "Wy", "Wz", "dWx_dx", "dWx_dy", "dWx_dz", "dWy_dx", "dWy_dy", "dWy_dz", "dWz_dx", "dWz_dy", "dWz_dz"):
+            setattr(self, name, 0.0)                                            # include/problem.h:99-102
+        # wind model 3 state (src/problem.cpp:371-460 fills it from MongoDB; synthetic here)
+        self.cache, self.cache_north, self.cache_east, self.cache_up = [], 0, 0, 0
+        self.xspacing = self.yspacing = self.zspacing = 150.0                   # include/problem.h:90-92
+        self.EastFromDatum = self.NorthFromDatum = self.UpFromDatum = 0.0
+
+    def set_wind_table(self, table):
+        names = ("u", "v", "w", "du_dx", "du_dy", "du_dz", "dv_dx", "dv_dy", "dv_dz", "dw_dx", "dw_dy", "dw_dz")
+        for f, name in enumerate(names):                                        # include/problem.h:103
+            setattr(self, name, [float(t) for t in table[f]])
+        self.Pwindmodel = 99                                                    # `default: break`, :732-735
+
+    def set_grid(self, v, origin, spacing, datum):
+        """cache[xi][yi][zi] = winddoc(x, y, z, u, v, w) on a regular ENU grid (include/problem.h:59-70)."""
+        nx, ny, nz = v.shape
+        self.cache = [[[NS(x=origin[0] + i * spacing[0], y=origin[1] + j * spacing[1], z=origin[2] + k * spacing[2],
+                           u=0.0, v=float(v[i, j, k]), w=0.0) for k in range(nz)] for j in range(ny)] for i in range(nx)]
+        # the reference's search loops bound the x index by cache_north and the y index by cache_east
+        # (src/problem.cpp:556-572); a cubic grid makes the two readings coincide
+        self.cache_north, self.cache_east, self.cache_up = nx, ny, nz
+        self.xspacing, self.yspacing, self.zspacing = (float(s) for s in spacing)
+        self.EastFromDatum, self.NorthFromDatum, self.UpFromDatum = (float(d) for d in datum)
+        self.Pwindmodel = 3
+
+
+def perturbed(x0, N, rng, scale=0.05):
+    """SURVEY.md section 8(c) recipe: every variable moved, z, Va, T put where wind and drag terms matter."""
+    x = np.array(x0) + scale * rng.uniform(-1, 1, len(x0)) * (1 + np.abs(x0))
+    node = x[1:].reshape(N + 1, 11)
+    node[:, 2] = rng.uniform(-70, -30, N + 1)
+    node[:, 3] = rng.uniform(12, 18, N + 1)
+    node[:, 10] = rng.uniform(5, 15, N + 1)
+    x[0] = abs(x[0]) + 0.01
+    return x
+
+
+def main():
+    t_start = time.time()
+    srcs = [open(os.path.join(REF, "src", f), errors="replace").read() for f in ("problem.cpp", "problemS10.cpp", "problemG7.cpp")]
+    it = cinterp.Interp(srcs)
+    out = {}
+    cases = []
+    airframes = ["tempest", "skywalker"]
+    spec = [  # (mission, N, airframe, goal (east, north, up, radius), start)
+        ("S10", 6, "tempest", (400.0, 0.0, 70.0, 100.0), (0.0, 0.0, 0.0)),
+        ("G7", 6, "tempest", (400.0, 0.0, 70.0, 0.0), (0.0, 0.0, 0.0)),
+        ("S10", 9, "skywalker", (250.0, -120.0, 70.0, 80.0), (15.0, -25.0, -40.0)),
+        ("G7", 9, "skywalker", (300.0, 200.0, 70.0, 0.0), (-20.0, 30.0, -55.0)),
+    ]
+    for ci, (mission, N, airframe, goal, start) in enumerate(spec):
+        rng = np.random.default_rng(4200 + ci)
+        ac15 = np.array(read_param_values(os.path.join(REF, "aircraft", airframe + ".param")))
+        lim8 = np.array(read_param_values(os.path.join(REF, "problems", mission, "limits.param")))
+        assert len(ac15) == 15 and len(lim8) == 8
+        if ci >= 2:     # perturbed air-frame coefficients: mass, area, e, AR, Cd0 all away from the shipped values
+            ac15[[0, 2, 3, 4, 5]] *= rng.uniform(0.8, 1.25, 5)
+        # non-shipped gains, all different and non-zero: kT kp kv ka kdt
+        gains = np.array([0.37, 5.3, 2.9, 0.0, 1.7]) * (1.0 + 0.1 * ci)
+        o = RefProblem(mission, N, aircraft_members(ac15), gains, lim8, goal, start)
+        tag = "c%d_" % ci
+        it.call(o, "InitialCond")
+        x0 = np.array(o.x)
+        it.call(o, "setLimits")
+        it.call(o, "countG", o.x)
+        neG = o.neG
+        out[tag + "meta"] = np.array([0 if mission == "S10" else 1, N, o.n, o.neF, neG])
+        out[tag + "ac15"], out[tag + "gains"], out[tag + "lim8"] = ac15, gains, lim8
+        out[tag + "goal"], out[tag + "start"] = np.array(goal), np.array(start)
+        out[tag + "chi_d"] = np.array([o.chi_d])
+        out[tag + "x0"] = x0
+        out[tag + "xlow"], out[tag + "xupp"] = np.array(o.xlow), np.array(o.xupp)
+        out[tag + "Flow"], out[tag + "Fupp"] = np.array(o.Flow), np.array(o.Fupp)
+        out[tag + "iGfun"] = np.array(o.iGfun[:neG], dtype=np.int32)
+        out[tag + "jGvar"] = np.array(o.jGvar[:neG], dtype=np.int32)
+        out[tag + "ioutput"] = np.frombuffer(it.output.files.get("Ioutput.txt", "").encode(), dtype=np.uint8)
+
+        # test points: (wind kind, x)
+        grid_v = rng.uniform(-6, 6, (4, 4, 4))
+        grid = dict(origin=(-260.0 + start[1], -240.0 + start[0], -30.0), spacing=(150.0, 150.0, 150.0), datum=(10.0, -20.0, 5.0))
+        points = [("shear", x0.copy(), None), ("shear", perturbed(x0, N, rng), None)]
+        for _ in range(3):
+            tbl = rng.uniform(-0.3, 0.3, (12, N + 1))
+            tbl[:3] *= 10.0
+            points.append(("table", perturbed(x0, N, rng), tbl))
+        points.append(("grid", perturbed(x0, N, rng), None))
+        X, Fs, Gs, kinds, tables, wouts = [], [], [], [], [], []
+        for kind, x, tbl in points:
+            if kind == "shear":
+                o.Pwindmodel = 1
+            elif kind == "table":
+                o.set_wind_table(tbl)
+            else:
+                o.set_grid(grid_v, grid["origin"], grid["spacing"], grid["datum"])
+            xl = [float(t) for t in x]
+            F, G = [0.0] * o.neF, [0.0] * neG
+            # src/DefineFG.cpp:24-37
+            it.call(o, "modelWind", xl)
+            it.call(o, "computeF", xl, F)
+            it.call(o, "computeG", xl, G)
+            X.append(x); Fs.append(F); Gs.append(G)
+            kinds.append({"shear": 1, "table": 99, "grid": 3}[kind])
+            tables.append(np.array([getattr(o, nm) for nm in ("u", "v", "w", "du_dx", "du_dy", "du_dz", "dv_dx", "dv_dy", "dv_dz", "dw_dx", "dw_dy", "dw_dz")]))
+            wouts.append(it.output.files.get("Woutput.txt", ""))
+        out[tag + "X"], out[tag + "F"], out[tag + "G"] = np.array(X), np.array(Fs), np.array(Gs)
+        out[tag + "windmodel"] = np.array(kinds)
+        out[tag + "wind"] = np.array(tables)          # the twelve member vectors as modelWind left them (ENU)
+        out[tag + "grid_v"] = grid_v
+        out[tag + "grid_geom"] = np.array(list(grid["origin"]) + list(grid["spacing"]) + list(grid["datum"]))
+        out[tag + "woutput0"] = np.frombuffer(wouts[0].encode(), dtype=np.uint8)   # Woutput.txt of the first point
+        cases.append(tag)
+        print("case %d %s N=%d %s: n=%d neF=%d neG=%d, %d points, %d interpreted calls, %.0f s" %
+              (ci, mission, N, airframe, o.n, o.neF, neG, len(points), it.calls, time.time() - t_start), flush=True)
+    out["cases"] = np.array(cases)
+    np.savez_compressed(OUT, **out)
+    print("wrote", OUT, os.path.getsize(OUT), "bytes")
+
+
+if __name__ == "__main__":
+    main()

@@ -7,6 +7,11 @@
 //   mode 0: every wave writes S KiB sequentially (S store instructions of 1 KiB) to segment = block id
 //   mode 1: groups of GRP consecutive waves share a GRP*S KiB region and interleave KiB chunks
 //   mode 2: like 0 but each store instruction is followed by `delay` x s_sleep (slow producer)
+//   mode 3/4/5: XCD-contiguous / mode 0 / mode 1 with non-temporal stores;  mode 6: 1 KiB read + S KiB nt stores
+//   mode 7: workgroups of GRP waves write one contiguous S KiB region together, KiB chunks interleaved over the waves
+//   mode 8: like 7 but wave w writes the w-th contiguous S/GRP KiB piece of the region
+//   mode 9: mode 4 after `delay` x 64 s_sleep(8) of idling (long-lived waves, short streams)
+//   mode 10: mode 7 where every wave first reads 1 KiB and idles `delay` x 64 s_sleep(8) (load -> compute -> store)
 // LDS bytes per block (dynamic) limit the occupancy like the real kernel's 22 KB does.
 //
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o tools/bin/wrbench tools/wrbench.cpp
@@ -20,11 +25,32 @@
 typedef double vec2 __attribute__((ext_vector_type(2)));
 
 template <int MODE>
+__global__ __launch_bounds__(512) void wrg(vec2 *out, int S, int grp, int delay, long nblocks)
+{
+    extern __shared__ char smem[];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long id = blockIdx.x;
+    vec2 v = {1.0 + lane, 2.0};
+    if (MODE == 10) {
+        const vec2 *in = reinterpret_cast<const vec2 *>(out) + (nblocks * (long)S + id * grp + w) * 64;
+        vec2 r = in[lane];
+        for (int d = 0; d < delay * 64; d++) __builtin_amdgcn_s_sleep(8);
+        v.x = r.x + r.y;
+    }
+    vec2 *base = out + id * S * 64;
+    if (MODE == 8) {
+        const int per = (S + grp - 1) / grp;
+        for (int i = w * per; i < min(S, (w + 1) * per); i++) __builtin_nontemporal_store(v, &base[(long)i * 64 + lane]);
+    } else {
+        for (int i = w; i < S; i += grp) __builtin_nontemporal_store(v, &base[(long)i * 64 + lane]);
+    }
+}
+
+template <int MODE>
 __global__ __launch_bounds__(64) void wr(vec2 *out, int S, int grp, int delay, long nblocks)
 {
     extern __shared__ char smem[];
     const int lane = threadIdx.x;
-    if (smem == nullptr) return;
     const long id = blockIdx.x;
     vec2 v = {1.0 + lane, 2.0};
     if (MODE == 1) {
@@ -44,6 +70,10 @@ __global__ __launch_bounds__(64) void wr(vec2 *out, int S, int grp, int delay, l
         double acc = r.x;
         for (int d = 0; d < delay * 64; d++) acc = acc * 1.0000001 + r.y;
         v.x = acc;
+        vec2 *base = out + id * S * 64;
+        for (int i = 0; i < S; i++) __builtin_nontemporal_store(v, &base[(long)i * 64 + lane]);
+    } else if (MODE == 9) {       // idle first, then S KiB nt stores
+        for (int d = 0; d < delay * 64; d++) __builtin_amdgcn_s_sleep(8);
         vec2 *base = out + id * S * 64;
         for (int i = 0; i < S; i++) __builtin_nontemporal_store(v, &base[(long)i * 64 + lane]);
     } else if (MODE == 5) {       // mode 1 (interleaved groups) with non-temporal stores
@@ -70,7 +100,7 @@ int main(int argc, char **argv)
     const long total = 800L << 20;
     const long nblocks = total / (1024L * S);
     vec2 *d;
-    CK(hipMalloc(&d, total + total / (S > 0 ? S : 1) + (4 << 20)));   // mode 6 reads 1 KiB per wave from behind the output
+    CK(hipMalloc(&d, total + (total / (S > 0 ? S : 1) + (4 << 20)) * (mode == 10 ? grp : 1)));   // modes 6, 10 read 1 KiB per wave from behind the output
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     auto launch = [&]() {
@@ -81,6 +111,10 @@ int main(int argc, char **argv)
         if (mode == 4) hipLaunchKernelGGL(wr<4>, dim3(nblocks), dim3(64), lds, 0, d, S, grp, delay, nblocks);
         if (mode == 6) hipLaunchKernelGGL(wr<6>, dim3(nblocks), dim3(64), lds, 0, d, S, grp, delay, nblocks);
         if (mode == 5) hipLaunchKernelGGL(wr<5>, dim3(nblocks / grp * grp), dim3(64), lds, 0, d, S, grp, delay, nblocks);
+        if (mode == 9) hipLaunchKernelGGL(wr<9>, dim3(nblocks), dim3(64), lds, 0, d, S, grp, delay, nblocks);
+        if (mode == 7) hipLaunchKernelGGL(wrg<7>, dim3(nblocks), dim3(64 * grp), lds, 0, d, S, grp, delay, nblocks);
+        if (mode == 8) hipLaunchKernelGGL(wrg<8>, dim3(nblocks), dim3(64 * grp), lds, 0, d, S, grp, delay, nblocks);
+        if (mode == 10) hipLaunchKernelGGL(wrg<10>, dim3(nblocks), dim3(64 * grp), lds, 0, d, S, grp, delay, nblocks);
     };
     for (int i = 0; i < 3; i++) launch();
     CK(hipDeviceSynchronize());
