@@ -1,16 +1,22 @@
 #!/usr/bin/env python3
 """bench.py -- collocation-node F/G+Jacobian evaluations per second on 1..8 MI355X.
 
-A step is ONE pass of the hot path over one device-resident batch: a single fused launch that
-evaluates F and G (objective, defects, boundary rows and the whole sparse Jacobian) of B
-trajectories per GPU, plus the gather of the per-trajectory objectives (on N > 1 GPUs that gather
-is one RCCL all-gather over xGMI, issued asynchronously so it overlaps the next step's launch).
-Inputs are resident in HBM before the timed region starts.
+A step is ONE pass of the hot path over one device-resident batch: a single launch that evaluates F
+and G (objective, defects, boundary rows and the whole sparse Jacobian) of B trajectories per GPU,
+plus the gather of the per-trajectory objectives (on N > 1 GPUs that gather is one RCCL all-gather
+over xGMI, issued asynchronously so it overlaps the next step's launch).  Inputs are resident in HBM
+before the timed region starts.
 
-Workload (BASELINE.json configs[1] batched as configs[3] prescribes): problemS10, tempest.param,
-ts = 200 collocation nodes, fp64; per-trajectory linear-shear wind Vref~U(0,5), href~U(5,20),
-start offset (xi,yi,zi)~U(-50,50)^2 x U(-100,-20), x = x0(start) + 5 % noise, seed 1000 + global
-trajectory index.  Weak scaling: B per GPU is fixed.
+Headline workload (BASELINE.json configs[1] batched as configs[3] prescribes): problemS10,
+tempest.param, ts = 200 collocation nodes, fp64; per-trajectory linear-shear wind Vref~U(0,5),
+href~U(5,20), start offset (xi,yi,zi)~U(-50,50)^2 x U(-100,-20), x = x0(start) + 5 % noise, seed
+1000 + global trajectory index.  Weak scaling by default
+(--batch trajectories per GPU); --global-batch G fixes the total instead (strong scaling: rank r
+owns shard_bounds(G, r, N)), which is how configs[3] (G = 1024) and configs[4] (G = 8192) are run
+as stated.
+
+On one GPU the JSON line also carries `configs`: one measured record per BASELINE config
+(device-resident evaluation and, for the single-trajectory configs, the host->host SNOPT callback).
 
 Launch: `python bench.py --gpus 1 ...` or, for N > 1,
 `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P
@@ -29,26 +35,74 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+AIRCRAFT5 = ("tempest", "skywalker", "tempest_eric", "tempest_wences", "tempest_will")
 
 
-def make_inputs(bt, tol_amd, B, first_index):
-    """Synthetic batch: trajectory table + X rows (host, float64)."""
-    trajs, X = [], np.empty((B, bt.n))
-    zis = np.empty(B)
+def make_trajectories(tol_amd, B, first_index, mission="S10", n_aircraft=1):
+    """The trajectory table of a synthetic batch (config 4 recipe; mission "mixed": b mod 2, air-frame b mod 5)."""
+    trajs = []
     for t in range(B):
-        rng = np.random.default_rng(1000 + first_index + t)
-        tr = tol_amd.Trajectory(aircraft=0, Vref=rng.uniform(0, 5), href=rng.uniform(5, 20),
-                                north_goal=0.0, east_goal=400.0, radius_goal=100.0,
-                                xi=rng.uniform(-50, 50), yi=rng.uniform(-50, 50))
-        zis[t] = rng.uniform(-100, -20)
-        trajs.append(tr)
-    bt.set_trajectories(trajs)
-    for t in range(B):
-        rng = np.random.default_rng(5000000 + first_index + t)
-        x = bt.x0(t, zi=zis[t])
-        X[t] = x + 0.05 * rng.uniform(-1, 1, x.shape) * (1 + np.abs(x))
-        X[t, 0] = abs(X[t, 0]) + 0.01
-    return trajs, X
+        g = first_index + t
+        rng = np.random.default_rng(1000 + g)
+        ms = ("S10", "G7")[g % 2] if mission == "mixed" else mission
+        trajs.append(tol_amd.Trajectory(aircraft=g % n_aircraft, mission=ms, Vref=rng.uniform(0, 5), href=rng.uniform(5, 20),
+                                        north_goal=0.0, east_goal=400.0, radius_goal=100.0 if ms == "S10" else 0.0,
+                                        xi=rng.uniform(-50, 50), yi=rng.uniform(-50, 50), zi=rng.uniform(-100, -20)))
+    return trajs
+
+
+def make_inputs(bt, torch, B, seed, buffers):
+    """X buffers in HBM: initial guesses generated on the device (tolfg_batch_x0_device) + 5 % noise; the
+    further buffers hold the same trajectories' vectors rotated by whole rows of the SAME mission/air-frame
+    class (10 rows), so that every row stays a valid input of its trajectory and no step re-reads a cached X."""
+    dX, dF, dG = bt.alloc(B)
+    bt.x0_device(dX)
+    gen = torch.Generator(device=dX.device).manual_seed(5000000 + seed)
+    noise = torch.rand(dX.shape, dtype=dX.dtype, device=dX.device, generator=gen) * 2 - 1
+    dt = dX[:, 0].clone()
+    dX += 0.05 * noise * (1 + dX.abs())
+    dX[:, 0] = dt.abs() + 0.01
+    dXs = [dX] + [torch.roll(dX, shifts=10 * (j + 1), dims=0).contiguous() for j in range(max(buffers, 1) - 1)]
+    for x in dXs[1:]:
+        x[:, 0] = dX[:, 0]
+    return dXs, dF, dG
+
+
+def timed_evals(bt, torch, dXs, dF, dG, B, steps, warmup, obj=None):
+    """`steps` evaluations back to back; wall time and the HIP-event time of every evaluation."""
+    for i in range(warmup):
+        bt.eval(dXs[i % len(dXs)], dF, dG, obj=obj, B=B)
+    torch.cuda.synchronize()
+    bt.set_timing(True)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        bt.eval(dXs[i % len(dXs)], dF, dG, obj=obj, B=B)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    n, avg_ms, min_ms = bt.kernel_time()
+    bt.set_timing(False)
+    assert n == steps
+    return wall, avg_ms, min_ms
+
+
+def device_record(tol_amd, torch, cfg, workload, mission, aircraft, ts, B, dtype, steps, device, x_buffers=4):
+    """One BASELINE config, device-resident on one GPU: whole-step rate and HIP-event time per evaluation."""
+    bt = tol_amd.Batch(mission, aircraft, ts=ts, dtype=dtype, device=device)
+    bt.set_trajectories(make_trajectories(tol_amd, B, 0, mission, len(aircraft)))
+    dXs, dF, dG = make_inputs(bt, torch, B, cfg, x_buffers)
+    obj = torch.empty(B, dtype=dF.dtype, device=dF.device)
+    wall, avg_ms, min_ms = timed_evals(bt, torch, dXs, dF, dG, B, steps, 5, obj)
+    assert torch.isfinite(obj).all()
+    alg = bt.algorithmic_bytes(B)
+    rec = {"config": cfg, "workload": workload, "mode": "device-resident", "batch": B, "ts": ts, "dtype": dtype, "steps": steps,
+           "ms_per_step": 1e3 * wall / steps, "node_evals_per_s": B * ts * steps / wall,
+           "eval_us": 1e3 * avg_ms, "eval_min_us": 1e3 * min_ms, "launches_per_step": 1,
+           "algorithmic_bytes": alg, "achieved_GBs": alg / (avg_ms * 1e-3) / 1e9,
+           "frac_of_hbm_peak": alg / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    bt.close()
+    del dXs, dF, dG
+    torch.cuda.empty_cache()
+    return rec
 
 
 def cpu_baseline(args, seconds):
@@ -99,10 +153,10 @@ def cpu_baseline(args, seconds):
     return base
 
 
-def callback_mode(tol_amd, mission, aircraft, ts, calls):
+def callback_mode(tol_amd, mission, aircraft, ts, calls, cfg=None):
     """Single-trajectory SNOPT-callback rate: host x -> host F, G through DEFINEGusrfg_, entered the
     way snOptA does (all arguments by reference, prepared once: the loop times the C ABI, not the
-    construction of ctypes objects)."""
+    construction of ctypes objects; F and G are the same arrays every call, as SNOPT's are)."""
     import ctypes as C
     p = tol_amd.Problem(mission, aircraft, ts=ts)
     p.make_current()
@@ -123,36 +177,27 @@ def callback_mode(tol_amd, mission, aircraft, ts, calls):
     dt = time.perf_counter() - t0
     assert st.value == 1 and np.isfinite(F).all()
     p.close()
-    return {"workload": f"{mission}/{aircraft}/ts={ts} single trajectory, DEFINEGusrfg_ host->host",
-            "us_per_call": 1e6 * dt / calls, "node_evals_per_s": calls * ts / dt, "calls": calls}
+    rec = {"workload": f"{mission}/{aircraft}/ts={ts} single trajectory, DEFINEGusrfg_ host->host (PCIe inclusive)",
+           "mode": "callback", "us_per_call": 1e6 * dt / calls, "node_evals_per_s": calls * ts / dt, "calls": calls}
+    if cfg is not None:
+        rec["config"] = cfg
+    return rec
 
 
-def compact_side_run(tol_amd, torch, args, dX, B, steps=50):
-    """SURVEY.md section 8(f) rank 1, measured beside the headline: the same batch through the compact
-    sparsity pattern (46 instead of 104 entries per node).  Not the headline metric -- it changes
-    the pattern handed to SNOPT."""
-    bc = tol_amd.Batch(args.mission, (args.aircraft,), ts=args.ts, dtype=args.dtype, device=dX.device.index,
-                       pattern="compact")
-    # same trajectories as the headline batch
-    import ctypes as C
-    from tol_amd import capi
-    make_inputs(bc, tol_amd, B, first_index=0)
-    _, dF, dG = bc.alloc(B)
-    obj = torch.empty(B, dtype=dF.dtype, device=dF.device)
-    for _ in range(5):
-        bc.eval(dX, dF, dG, obj=obj)
-    torch.cuda.synchronize()
-    bc.set_timing(True)
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        bc.eval(dX, dF, dG, obj=obj)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    _, kms, _ = bc.kernel_time()
-    alg = bc.algorithmic_bytes(B)
-    return {"value": B * args.ts * steps / dt, "unit": "node-evals/s", "steps": steps, "ms_per_step": 1e3 * dt / steps,
-            "kernel_ms": kms, "algorithmic_bytes_per_launch": alg, "achieved_GBs": alg / (kms * 1e-3) / 1e9,
-            "frac_of_hbm_peak": alg / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, "bytes_per_node": alg / (B * args.ts)}
+def config_records(tol_amd, torch, device):
+    """BASELINE.json configs, each on ONE GPU at its own sizes.  configs[0] is the CPU/SNOPT
+    plumbing case (tests/test_cpp_plumbing.py); configs[3] and [4] also at the share one of 8 GPUs gets."""
+    recs = []
+    recs.append(device_record(tol_amd, torch, 1, "configs[1] problemS10/tempest/ts=200, one trajectory", "S10", ("tempest",), 200, 1, "f64", 200, device, 1))
+    recs.append(callback_mode(tol_amd, "S10", "tempest", 200, 400, cfg=1))
+    recs.append(device_record(tol_amd, torch, 2, "configs[2] problemS10/skywalker/ts=2000, one trajectory", "S10", ("skywalker",), 2000, 1, "f64", 200, device, 1))
+    recs.append(callback_mode(tol_amd, "S10", "skywalker", 2000, 200, cfg=2))
+    recs.append(device_record(tol_amd, torch, 3, "configs[3] batch=1024 problemS10 ts=200, randomized wind/IC", "S10", ("tempest",), 200, 1024, "f64", 100, device))
+    recs.append(device_record(tol_amd, torch, 3, "configs[3] share of one of 8 GPUs: batch=128", "S10", ("tempest",), 200, 128, "f64", 200, device))
+    for dtype in ("f64", "f32"):
+        recs.append(device_record(tol_amd, torch, 4, "configs[4] mixed G7+S10 batch=8192, five air-frames, ts=200, one launch", "mixed", AIRCRAFT5, 200, 8192, dtype, 50, device))
+        recs.append(device_record(tol_amd, torch, 4, "configs[4] share of one of 8 GPUs: batch=1024", "mixed", AIRCRAFT5, 200, 1024, dtype, 100, device))
+    return recs
 
 
 def main():
@@ -160,28 +205,30 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--batch", type=int, default=4096, help="trajectories per GPU")
+    ap.add_argument("--batch", type=int, default=4096, help="trajectories per GPU (weak scaling)")
+    ap.add_argument("--global-batch", type=int, default=0,
+                    help="total trajectories over all GPUs (strong scaling; configs[3]: 1024, configs[4]: 8192 with --mission mixed)")
     ap.add_argument("--ts", type=int, default=200)
-    ap.add_argument("--mission", default="S10")
-    ap.add_argument("--aircraft", default="tempest")
+    ap.add_argument("--mission", default="S10", choices=["S10", "G7", "mixed"])
+    ap.add_argument("--aircraft", default="tempest", help="air-frame; a mixed batch uses all five")
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-callback", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the per-BASELINE-config records and side runs")
     ap.add_argument("--x-buffers", type=int, default=4,
                     help="distinct input batches rotated over the steps; 4 x 72 MB exceed the 256 MiB Infinity "
                          "Cache, so every step reads its X from HBM rather than from a cache that kept it")
-    ap.add_argument("--ld-pad", type=int, default=0, help="pad the row strides of X, F, G to this many elements (0 = 16 bytes)")
     ap.add_argument("--pattern", default="reference", choices=["reference", "compact"],
                     help="Jacobian sparsity pattern; the headline metric is quoted on the reference's own pattern")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
-                    help="collective backend for N > 1; gloo (objectives staged through host memory) only "
-                         "rehearses the multi-rank step loop when several ranks must share one GPU")
+                    help="collective backend for N > 1: nccl = RCCL over xGMI; gloo (objectives staged through host "
+                         "memory) only rehearses the multi-rank step loop, e.g. several ranks sharing one GPU")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
     import tol_amd
+    from tol_amd.distributed import shard_bounds
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -198,43 +245,46 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
-            try:      # eager communicator creation on this rank's GPU (RCCL over xGMI)
-                dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-            except TypeError:
-                dist.init_process_group("nccl")
-            # first collective here, outside any timing: RCCL builds its rings lazily; if it cannot
-            # (driver / IPC trouble) the run falls back to gloo rather than losing the scaling point
+            # eager communicator creation on this rank's GPU (RCCL over xGMI) and a first collective outside any
+            # timing (RCCL builds its rings lazily).  A failure here is fatal: a scaling point measured over a
+            # host-staged fallback would not be "RCCL over xGMI"; gloo is only ever chosen with --backend gloo.
             try:
+                try:
+                    dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+                except TypeError:
+                    dist.init_process_group("nccl")
                 probe = torch.ones(1, device="cuda")
                 dist.all_reduce(probe)
                 torch.cuda.synchronize()
+                assert int(probe.item()) == world
             except Exception as exc:      # noqa: BLE001
-                sys.stderr.write(f"bench.py: RCCL collective failed ({exc}); falling back to gloo\n")
-                dist.destroy_process_group()
-                dist.init_process_group("gloo")
-                args.backend = "gloo"
+                sys.stderr.write(f"bench.py rank {rank}: RCCL is not usable here: {type(exc).__name__}: {exc}\n"
+                                 f"  (no fallback is taken; rerun with --backend gloo only to rehearse the step loop)\n")
+                sys.stderr.flush()
+                os._exit(3)
         else:
             dist.init_process_group("gloo")
 
-    B = args.batch
-    bt = tol_amd.Batch(args.mission, (args.aircraft,), ts=args.ts, dtype=args.dtype, device=local, pattern=args.pattern)
-    _, X = make_inputs(bt, tol_amd, B, first_index=rank * B)
-    dX, dF, dG = bt.alloc(B, pad=(args.ld_pad or None))
-    dX[:, :bt.n] = torch.from_numpy(X).to(bt.torch_dtype()).cuda()
-    del X
-    # further input batches: the same trajectories, the decision vectors rotated by whole rows
-    # (every row is a valid input of ITS trajectory's shape; values differ from step to step)
-    dXs = [dX] + [torch.roll(dX, shifts=7 * (j + 1), dims=0).contiguous() for j in range(max(args.x_buffers, 1) - 1)]
-    obj = [torch.empty(B, dtype=dF.dtype, device=dF.device) for _ in range(2)]
+    aircraft = AIRCRAFT5 if args.mission == "mixed" else (args.aircraft,)
+    if args.global_batch > 0:
+        lo, hi = shard_bounds(args.global_batch, rank, world)
+        B, first, total, scaling = hi - lo, lo, args.global_batch, "strong"
+    else:
+        B, first, total, scaling = args.batch, rank * args.batch, args.batch * world, "weak"
+    Bmax = shard_bounds(total, 0, world)[1] if args.global_batch > 0 else B      # widest shard (gather buffer)
+    bt = tol_amd.Batch(args.mission, aircraft, ts=args.ts, dtype=args.dtype, device=local, pattern=args.pattern)
+    bt.set_trajectories(make_trajectories(tol_amd, B, first, args.mission, len(aircraft)))
+    dXs, dF, dG = make_inputs(bt, torch, B, first, args.x_buffers)
+    obj = [torch.zeros(Bmax, dtype=dF.dtype, device=dF.device) for _ in range(2)]
     gdev = dF.device if args.backend == "nccl" else torch.device("cpu")
-    allobj = [torch.empty(B * world, dtype=dF.dtype, device=gdev) for _ in range(2)] if world > 1 else None
+    allobj = [torch.empty(Bmax * world, dtype=dF.dtype, device=gdev) for _ in range(2)] if world > 1 else None
     pending = [None, None]
 
     def step(i):
         s = i & 1
         if world > 1 and pending[s] is not None:
             pending[s].wait()                      # buffer reuse: the gather of step i-2 must be done
-        bt.eval(dXs[i % len(dXs)], dF, dG, obj=obj[s])   # finalize_kernel also writes the objectives, contiguous
+        bt.eval(dXs[i % len(dXs)], dF, dG, obj=obj[s], B=B)     # the finalizing waves also write the objectives, contiguous
         if world > 1:
             src = obj[s] if args.backend == "nccl" else obj[s].cpu()
             pending[s] = dist.all_gather_into_tensor(allobj[s], src, async_op=True)
@@ -255,8 +305,8 @@ def main():
     for i in range(args.warmup):
         step(i)
     fence()
-    # HIP events on the launch stream around the dominant kernel of every timed step (recorded
-    # inside the library, include/tolfg.h: tolfg_batch_set_timing)
+    # HIP events on the launch stream around every timed evaluation (recorded inside the library,
+    # include/tolfg.h: tolfg_batch_set_timing)
     bt.set_timing(True)
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -271,57 +321,77 @@ def main():
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed, kern_ms = el[0].item(), el[1].item()
 
-    # sanity: the objectives that came back are finite and, on N > 1, every rank's shard arrived
-    final = allobj[(args.steps - 1) & 1] if world > 1 else obj[(args.steps - 1) & 1]
-    assert torch.isfinite(final).all(), "non-finite objective in the gathered result"
-    if world > 1:   # this rank's shard sits at its place in the gathered vector
-        mine = obj[(args.steps - 1) & 1].to(final.device)
-        assert torch.equal(final[rank * B:(rank + 1) * B], mine), "gathered objectives are out of order"
+    # sanity: the objectives that came back are finite and, on N > 1, every rank's shard arrived in place
+    last = (args.steps - 1) & 1
+    assert torch.isfinite(obj[last][:B]).all(), "non-finite objective"
+    if world > 1:
+        mine = obj[last].to(allobj[last].device)
+        assert torch.equal(allobj[last][rank * Bmax:(rank + 1) * Bmax], mine), "gathered objectives are out of order"
 
     if rank == 0:
-        nodes_per_step = B * world * args.ts
+        nodes_per_step = total * args.ts
         value = nodes_per_step * args.steps / elapsed
         alg_bytes = bt.algorithmic_bytes(B)
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
-        traffic = None
+        traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tpath):
             try:
                 with open(tpath) as fh:
                     tj = json.load(fh)
-                if tj.get("batch") == B and tj.get("ts") == args.ts and tj.get("dtype") == args.dtype:
+                if (tj.get("batch") == B and tj.get("ts") == args.ts and tj.get("dtype") == args.dtype
+                        and tj.get("mission", "S10") == args.mission and tj.get("pattern", "reference") == args.pattern):
                     traffic = tj.get("hbm_bytes_per_launch")
+                    traffic_source = "profiles/traffic_latest.json (replayed: PMC passes of " + str(tj.get("source", "tools/profile_gpu.sh")) + ", not measured in this run)"
             except (OSError, ValueError):
                 traffic = None
+        backend = "none (single GPU)" if world == 1 else ("rccl" if args.backend == "nccl" else "gloo (host-staged rehearsal)")
         line = {
             "metric": "collocation-node F/G+Jacobian evals/sec",
             "value": value, "unit": "node-evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"problem{args.mission}/{args.aircraft}.param/ts={args.ts} (BASELINE configs[1]) as a "
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": scaling,
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic", "backend": backend,
+            "config": {"workload": f"problem{args.mission}/{'+'.join(aircraft)}.param/ts={args.ts} (BASELINE configs[1]) as a "
                                    f"device-resident batch of {B} trajectories per GPU with randomized shear wind and "
-                                   f"start offsets (configs[3] recipe); one fused F+G launch + objective gather per step",
-                       "mission": args.mission, "aircraft": args.aircraft, "ts": args.ts, "pattern": args.pattern,
-                       "batch_per_gpu": B, "global_batch": B * world, "x_buffers": len(dXs),
-                       "parallelism": (f"batch-sharded x{world}, " + ("RCCL" if args.backend == "nccl" else "gloo (host-staged)") +
-                                       " all-gather of objectives") if world > 1 else "single GPU"},
+                                   f"start offsets (configs[3] recipe); one F+G launch + objective gather per step",
+                       "mission": args.mission, "aircraft": "+".join(aircraft), "ts": args.ts, "pattern": args.pattern,
+                       "batch_per_gpu": B, "global_batch": total, "x_buffers": len(dXs),
+                       "parallelism": (f"batch-sharded x{world}, {backend} all-gather of objectives") if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "tolfg::fg_kernel", "kernel_ms": kern_ms, "kernel_min_ms": kern_min_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                         "kernel": "tolfg::fg_kernel (the whole evaluation: the last tile wave of a trajectory finalizes it)",
+                         "kernel_ms": kern_ms, "kernel_min_ms": kern_min_ms, "algorithmic_bytes_per_launch": alg_bytes,
                          "bytes_per_node": alg_bytes / (B * args.ts)},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
-        if world == 1 and args.pattern == "reference" and not args.no_callback:
-            line["next_compact_pattern"] = compact_side_run(tol_amd, torch, args, dX, B)
-        if world == 1 and not args.no_callback:
-            line["callback"] = [callback_mode(tol_amd, "S10", "tempest", 200, 300),
-                                callback_mode(tol_amd, "S10", "skywalker", 2000, 100)]
+        if world == 1 and not args.no_configs:
+            del dXs, dF, dG
+            torch.cuda.empty_cache()
+            line["configs"] = config_records(tol_amd, torch, local)
+            line["callback"] = [r for r in line["configs"] if r["mode"] == "callback"]
+            if args.pattern == "reference" and args.mission != "mixed":
+                line["next_compact_pattern"] = compact_side_run(tol_amd, torch, args, B, local)
         print(json.dumps(line), flush=True)
 
     if world > 1:
         fence()
         dist.destroy_process_group()
+
+
+def compact_side_run(tol_amd, torch, args, B, device, steps=50):
+    """SURVEY.md section 8(f) rank 1, measured beside the headline: the same batch through the compact
+    sparsity pattern (46 instead of 104 entries per node).  Not the headline metric -- it changes
+    the pattern handed to SNOPT."""
+    bc = tol_amd.Batch(args.mission, (args.aircraft,), ts=args.ts, dtype=args.dtype, device=device, pattern="compact")
+    bc.set_trajectories(make_trajectories(tol_amd, B, 0, args.mission, 1))
+    dXs, dF, dG = make_inputs(bc, torch, B, 0, args.x_buffers)
+    obj = torch.empty(B, dtype=dF.dtype, device=dF.device)
+    wall, kms, _ = timed_evals(bc, torch, dXs, dF, dG, B, steps, 5, obj)
+    alg = bc.algorithmic_bytes(B)
+    return {"value": B * args.ts * steps / wall, "unit": "node-evals/s", "steps": steps, "ms_per_step": 1e3 * wall / steps,
+            "kernel_ms": kms, "algorithmic_bytes_per_launch": alg, "achieved_GBs": alg / (kms * 1e-3) / 1e9,
+            "frac_of_hbm_peak": alg / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, "bytes_per_node": alg / (B * args.ts)}
 
 
 if __name__ == "__main__":

@@ -87,8 +87,9 @@ typedef struct tolfg_config {
     double Vref, href;        /* shear wind constants, 2.4 and 10 (ref: src/problem.cpp:504-505)   */
     double xi, yi, zi;        /* start position, 0,0,0 (ref: src/problem.cpp:83-85,111-113)        */
     int    device;            /* HIP device ordinal                                                */
-    int    debug_dumps;       /* 1 = also rewrite Xoutput/Foutput/Goutput.txt each call like the
-                                 reference does (src/DefineFG.cpp:16-46); default 0                */
+    int    debug_dumps;       /* 1 = also rewrite Xoutput/Foutput/Goutput.txt and Woutput.txt each call like
+                                 the reference does (src/DefineFG.cpp:16-46, src/problem.cpp:740-756);
+                                 default 0                                                          */
     int    pattern;           /* TOLFG_PATTERN_*; default REFERENCE                                */
 } tolfg_config;
 
@@ -160,10 +161,12 @@ int tolfg_computeG(tolfg_problem *p, const double *x, double *G);
 
 /* ------------------------------------------------------------------ 3. batched evaluation */
 
-/* One trajectory of a batch.  All trajectories of a batch share mission and ts. */
+/* One trajectory of a batch.  All trajectories of a batch share ts; they share the mission too unless
+ * the batch was created with mission "mixed", in which case `mission` selects it per trajectory. */
+enum { TOLFG_MISSION_S10 = 0, TOLFG_MISSION_G7 = 1 };
 typedef struct tolfg_traj {
     int    aircraft;          /* index into tolfg_batch_config.aircraft[]                          */
-    int    reserved;
+    int    mission;           /* TOLFG_MISSION_*; read only by "mixed" batches                     */
     double Vref, href;        /* shear wind of this trajectory (TOLFG_WIND_SHEAR)                  */
     double north_goal, east_goal, radius_goal;
     double xi, yi;            /* start position: G7's course chi_d = atan2(yg-yi, xg-xi)           */
@@ -171,7 +174,9 @@ typedef struct tolfg_traj {
 } tolfg_traj;
 
 typedef struct tolfg_batch_config {
-    const char        *mission;
+    const char        *mission;       /* "S10" | "G7" | "mixed" (BASELINE configs[4]: G7 and S10 trajectories
+                                         evaluated by ONE launch; every row of X/F/G keeps its own mission's
+                                         SNOPT layout, rows are strided for the larger mission)          */
     const char        *root_path;     /* NULL = shipped data                                      */
     const char *const *aircraft;      /* aircraft table: names of .param files                     */
     int                n_aircraft;    /* 1..8                                                      */
@@ -186,8 +191,13 @@ typedef struct tolfg_batch tolfg_batch;
 
 int  tolfg_batch_create(const tolfg_batch_config *cfg, tolfg_batch **out);
 void tolfg_batch_destroy(tolfg_batch *b);
+/* Row sizes to allocate for (a mixed batch: the larger of the two missions per quantity) and the
+ * pattern of a single-mission batch. */
 int  tolfg_batch_sizes(const tolfg_batch *b, int *n, int *neF, int *neG);
 int  tolfg_batch_pattern(const tolfg_batch *b, int *iGfun, int *jGvar);
+/* The same per mission (TOLFG_MISSION_*), for the rows of a mixed batch. */
+int  tolfg_batch_mission_sizes(const tolfg_batch *b, int mission, int *n, int *neF, int *neG);
+int  tolfg_batch_mission_pattern(const tolfg_batch *b, int mission, int *iGfun, int *jGvar);
 /* Describe (or re-describe) the B trajectories; uploads a small per-trajectory table. */
 int  tolfg_batch_set_trajectories(tolfg_batch *b, int B, const tolfg_traj *trajs);
 /* one gridded wind field for the whole batch (TOLFG_WIND_GRID); copied to the device */
@@ -205,6 +215,11 @@ int  tolfg_batch_bounds_device(tolfg_batch *b, int B, void *dXlow, void *dXupp, 
 int  tolfg_batch_bounds(const tolfg_batch *b, int t, double zi,
                         double *xlow, double *xupp, double *Flow, double *Fupp);
 
+/* Stream contract: a batch owns per-launch workspace (objective partials, arrival counters), so its
+ * evaluations must be issued on ONE stream at a time, and a stream synchronisation must separate the last
+ * evaluation from tolfg_batch_set_trajectories / tolfg_batch_set_wind_grid (they copy on the null stream).
+ * The first evaluation of a batch (and one with a larger B than before) allocates and uploads; do not
+ * issue it inside a hipGraph capture -- warm up once, then capture (tests/test_gpu_parity.py does). */
 /* Evaluate F and G of trajectories [0,B) in one launch.  dX, dF, dG, dWind are DEVICE pointers to
  * elements of the batch dtype; row t of X/F/G starts ldx/ldf/ldg elements after row t-1
  * (ld >= n / neF / neG; even ld keeps 16-byte stores).  dWind is NULL unless windmodel is
@@ -226,8 +241,8 @@ int  tolfg_batch_objectives(tolfg_batch *b, int B, const void *dF, long ldf, voi
 int  tolfg_batch_set_timing(tolfg_batch *b, int enable);
 int  tolfg_batch_kernel_time(tolfg_batch *b, double *avg_ms, double *min_ms);
 
-/* algorithmic bytes one evaluation of B trajectories moves: elemsize * B * (n + neF + neG)
- * (SURVEY.md section 8d), with neG of the batch's pattern */
+/* algorithmic bytes one evaluation of trajectories [0,B) moves: elemsize * sum of (n + neF + neG)
+ * (SURVEY.md section 8d), with each trajectory's own mission sizes and the batch's pattern */
 double tolfg_batch_algorithmic_bytes(const tolfg_batch *b, int B);
 
 /* ------------------------------------------------------------------ misc */

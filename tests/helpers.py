@@ -29,3 +29,32 @@ def random_wind_table(N, seed, scale=0.3):
     w = rng.uniform(-scale, scale, (12, N + 1))
     w[:3] *= 10.0
     return w
+
+
+# ---- fp32 I/O variant: bounds per row class, about 4x the worst case measured on the mixed 8192-trajectory
+# batch (profiles/r01_fp32_sweep.md, re-measured profiles/r02_fp32_sweep.md): objective 2.1e-7,
+# x/y/z defects 9.4e-6, Va/gam/chi defects 1.6e-6, phi/CL defects 4.8e-7, boundary rows 4.1e-6 (scaled).
+FP32_TOL = {"objective": 1e-6, "r1-r3": 4e-5, "r4-r6": 8e-6, "r7-r8": 2e-6, "boundary": 2e-5}
+
+
+def row_class_masks(rows, N):
+    """class name -> boolean mask over an array of F-row indices (np.arange(neF) for F, iGfun for G)."""
+    rows = np.asarray(rows)
+    r = (rows - 1) % 8 + 1
+    dyn = (rows >= 1) & (rows < 8 * N + 1)
+    return {"objective": rows == 0, "r1-r3": dyn & (r <= 3), "r4-r6": dyn & (r >= 4) & (r <= 6),
+            "r7-r8": dyn & (r >= 7), "boundary": rows >= 8 * N + 1}
+
+
+def assert_close_f32(F, G, Fo, Go, iG, N, mask=None, what="", scale=1.0):
+    """fp32 outputs against the fp64 oracle evaluated at the same (float32-rounded) inputs, per row class.
+    `scale` loosens every class bound by a stated factor for inputs harsher than the sweep's."""
+    worst = {}
+    for arr, ref, rows, msk, tag in ((F, Fo, np.arange(len(Fo)), None, "F"), (G, Go, iG, mask, "G")):
+        for cname, m in row_class_masks(rows, N).items():
+            if not m.any():
+                continue
+            sub = None if msk is None else msk[m]
+            worst[(tag, cname)] = assert_close(np.asarray(arr)[m], np.asarray(ref)[m], tol=scale * FP32_TOL[cname], mask=sub,
+                                               what=f"{what} {tag} class {cname}")
+    return worst

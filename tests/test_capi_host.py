@@ -140,3 +140,54 @@ def test_batch_eval_argument_checks_need_no_gpu(tolfg):
     assert L.tolfg_batch_eval(bt2._h, 1, dummy, n, dummy, neF, dummy, neG, None, 1, 1, None, None) == -1   # table wind without a table
     assert L.tolfg_batch_x0_device(h, 3, None, n, None) == -1
     assert L.tolfg_write_json(None, None, 0.0, None) == -1
+
+
+def test_python_layer_refuses_wrong_tensors_without_a_gpu(tolfg):
+    """Batch.eval and friends check dtype, device, shape and strides before handing raw pointers to the C ABI
+    (a float32 tensor given to an f64 batch would make the kernels write out of bounds)."""
+    import torch
+    bt = tolfg.Batch("S10", ["tempest"], ts=10)
+    bt.set_trajectories([tolfg.Trajectory() for _ in range(3)])
+    good = lambda c, dt=torch.float64: torch.zeros((3, c), dtype=dt)   # noqa: E731  (CPU tensors: wrong device)
+    with pytest.raises(tolfg.TolfgError) as e:
+        bt.eval(good(bt.n), good(bt.neF), good(bt.neG))
+    assert e.value.code == tolfg.capi.ERR_ARG and "lives on" in str(e.value)
+    with pytest.raises(tolfg.TolfgError) as e:
+        bt.eval(good(bt.n, torch.float32), good(bt.neF), good(bt.neG))
+    assert "dtype" in str(e.value)
+    with pytest.raises(tolfg.TolfgError):
+        bt.eval(np.zeros((3, bt.n)), good(bt.neF), good(bt.neG))
+    with pytest.raises(tolfg.TolfgError):
+        bt.x0_device(good(bt.n - 1))
+    with pytest.raises(tolfg.TolfgError):
+        bt.objectives(good(bt.neF))
+    with pytest.raises(tolfg.TolfgError):
+        bt.bounds_device(good(bt.n), good(bt.n), good(bt.neF), good(bt.neF))
+
+
+def test_mixed_batch_set_up_needs_no_gpu(tolfg, oracle):
+    """A "mixed" batch: per-mission sizes and patterns, per-trajectory x0 and bounds, argument checks."""
+    bt = tolfg.Batch("mixed", ["tempest", "skywalker"], ts=20)
+    nS, fS, gS = bt.sizes_of("S10")
+    nG, fG, gG = bt.sizes_of("G7")
+    assert (nS, fS, gS) == oracle.sizes("S10", 20) and (nG, fG, gG) == oracle.sizes("G7", 20)
+    assert (bt.n, bt.neF, bt.neG) == (nS, max(fS, fG), max(gS, gG))
+    for m in ("S10", "G7"):
+        iG, jG = bt.pattern(m)
+        oi, oj = oracle.Problem(m, N=20).pattern()
+        assert np.array_equal(iG, oi) and np.array_equal(jG, oj)
+    with pytest.raises(tolfg.TolfgError):
+        bt.pattern()                                   # one pattern per mission
+    trajs = [tolfg.Trajectory(aircraft=t % 2, mission=("S10", "G7")[t % 2], radius_goal=100.0 * (1 - t % 2), xi=3.0 * t, yi=-2.0 * t)
+             for t in range(4)]
+    bt.set_trajectories(trajs)
+    for t, tr in enumerate(trajs):
+        o = oracle.Problem(tr.mission, ("tempest", "skywalker")[t % 2], N=20, radius_goal=tr.radius_goal, start=(tr.xi, tr.yi, -30.0))
+        n = bt.sizes_of(tr.mission)[0]
+        assert np.array_equal(bt.x0(t, zi=-30.0)[:n], o.x0())
+        for a, b in zip(bt.bounds(t, zi=-30.0), o.bounds()):
+            assert np.array_equal(a[:len(b)], b)
+    assert tolfg.lib().tolfg_batch_algorithmic_bytes(bt._h, 4) == 8.0 * (2 * (nS + fS + gS) + 2 * (nG + fG + gG))
+    single = tolfg.Batch("S10", ["tempest"], ts=20)
+    with pytest.raises(tolfg.TolfgError):
+        single.sizes_of("G7")

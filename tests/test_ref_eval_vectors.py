@@ -142,6 +142,21 @@ def test_hip_path_matches_the_reference_evaluation(tolfg, oracle, tmp_path, tag)
             p.set_wind_table(wind[i])
         elif kind == 3:
             p.set_wind_grid(z[tag + "grid_v"], origin=tuple(geom[0:3]), spacing=tuple(geom[3:6]), datum=tuple(geom[6:9]))
+        if i == 0:
+            # the four text dumps of a reference call (opt-in here): Woutput.txt must equal, byte for byte, what the
+            # reference's modelWind wrote for this point (src/problem.cpp:740-756)
+            pd = tolfg.Problem(mission, "fixture", east_goal=east_goal, north_goal=north_goal, up_goal=up_goal, radius_goal=radius,
+                               start=start, root_path=root, debug_dumps=True)
+            cwd = os.getcwd()
+            os.chdir(tmp_path)
+            try:
+                pd.define_fg(X[i])
+            finally:
+                os.chdir(cwd)
+            pd.close()
+            assert (tmp_path / "Woutput.txt").read_bytes() == z[tag + "woutput0"].tobytes()
+            for name, cnt in (("Xoutput.txt", p.n), ("Foutput.txt", p.neF), ("Goutput.txt", p.neG)):
+                assert len((tmp_path / name).read_text().split()) == cnt
         F, G, st = p.define_fg(X[i])
         assert st == 1
         undefined = np.isnan(Gr[i])

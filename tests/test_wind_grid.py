@@ -6,7 +6,7 @@ only where the reference freezes the wind), and the HIP path equals the oracle."
 import numpy as np
 import pytest
 
-from helpers import assert_close
+from helpers import assert_close, assert_close_f32
 
 
 def make_grid(seed, nx=7, ny=6, nz=4, linear=None):
@@ -96,15 +96,21 @@ def test_batch_grid_wind_matches_oracle(tolfg, oracle, dtype):
     bt.eval(dX, dF, dG)
     torch.cuda.synchronize()
     Xs = dX[:, :bt.n].double().cpu().numpy()
-    tol = 1e-12 if dtype == "f64" else 5e-3
+    iG, _ = bt.pattern()
     for t in range(B):
         Fo, Go = ops[t].eval(Xs[t])
         if dtype == "f32":        # the float kernel interpolates a float32 copy of the grid
             g32 = dict(g, v=g["v"].astype(np.float32).astype(np.float64))
             Fo, Go = oracle.Problem("S10", ("tempest", "skywalker")[t % 2], N=N, start=(trajs[t].xi, trajs[t].yi, -50.0),
                                     wind_grid=g32).eval(Xs[t])
-        assert_close(dF[t, :bt.neF].double().cpu().numpy(), Fo, tol=tol, what=f"grid batch F[{t}]")
-        assert_close(dG[t, :bt.neG].double().cpu().numpy(), Go, tol=tol, mask=ops[t].undefined_mask(), what=f"grid batch G[{t}]")
+        Ft, Gt = dF[t, :bt.neF].double().cpu().numpy(), dG[t, :bt.neG].double().cpu().numpy()
+        if dtype == "f64":
+            assert_close(Ft, Fo, what=f"grid batch F[{t}]")
+            assert_close(Gt, Go, mask=ops[t].undefined_mask(), what=f"grid batch G[{t}]")
+        else:
+            # the float kernel also forms the cell coordinates and shape functions in float32 from positions
+            # of a few hundred metres: 4x the per-class bounds of the shear-wind sweep
+            assert_close_f32(Ft, Gt, Fo, Go, iG, N, mask=ops[t].undefined_mask(), what=f"grid batch f32 [{t}]", scale=4.0)
 
 
 def test_bad_grid_is_rejected(tolfg):

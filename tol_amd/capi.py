@@ -9,6 +9,8 @@ WIND_NONE, WIND_SHEAR, WIND_GRID, WIND_TABLE = 0, 1, 3, 99
 F64, F32 = 0, 1
 PATTERN_REFERENCE, PATTERN_COMPACT = 0, 1
 PATTERNS = {"reference": 0, "compact": 1}
+MISSION_S10, MISSION_G7 = 0, 1
+MISSIONS = {"S10": 0, "G7": 1}
 IU_MAGIC = 0x70F6
 
 _dp = C.POINTER(C.c_double)
@@ -33,7 +35,7 @@ class Config(C.Structure):
 
 
 class Traj(C.Structure):
-    _fields_ = [("aircraft", C.c_int), ("reserved", C.c_int),
+    _fields_ = [("aircraft", C.c_int), ("mission", C.c_int),
                 ("Vref", C.c_double), ("href", C.c_double),
                 ("north_goal", C.c_double), ("east_goal", C.c_double), ("radius_goal", C.c_double),
                 ("xi", C.c_double), ("yi", C.c_double), ("zi", C.c_double)]
@@ -86,6 +88,8 @@ SYMBOLS = {
     "tolfg_batch_destroy": (None, [C.c_void_p]),
     "tolfg_batch_sizes": (C.c_int, [C.c_void_p, _ip, _ip, _ip]),
     "tolfg_batch_pattern": (C.c_int, [C.c_void_p, _ip, _ip]),
+    "tolfg_batch_mission_sizes": (C.c_int, [C.c_void_p, C.c_int, _ip, _ip, _ip]),
+    "tolfg_batch_mission_pattern": (C.c_int, [C.c_void_p, C.c_int, _ip, _ip]),
     "tolfg_batch_set_trajectories": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(Traj)]),
     "tolfg_batch_x0": (C.c_int, [C.c_void_p, C.c_int, C.c_double, _dp]),
     "tolfg_batch_x0_device": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_long, C.c_void_p]),

@@ -279,8 +279,26 @@ int tolfg_batch_sizes(const tolfg_batch *h, int *n, int *neF, int *neG)
 int tolfg_batch_pattern(const tolfg_batch *h, int *iGfun, int *jGvar)
 {
     if (!h || !iGfun || !jGvar) return fail(TOLFG_ERR_ARG, "null argument");
+    if (h->b->mission() == MISSION_MIXED) return fail(TOLFG_ERR_ARG, "a mixed batch has one pattern per mission: tolfg_batch_mission_pattern");
     make_pattern(h->b->sizes(), iGfun, jGvar);
     return TOLFG_OK;
+}
+
+int tolfg_batch_mission_sizes(const tolfg_batch *h, int mission, int *n, int *neF, int *neG)
+{
+    if (!h) return fail(TOLFG_ERR_ARG, "null batch");
+    return guarded([&] {
+        const Sizes &s = h->b->sizes_of(mission);
+        if (n) *n = s.n;
+        if (neF) *neF = s.neF;
+        if (neG) *neG = s.neG;
+    });
+}
+
+int tolfg_batch_mission_pattern(const tolfg_batch *h, int mission, int *iGfun, int *jGvar)
+{
+    if (!h || !iGfun || !jGvar) return fail(TOLFG_ERR_ARG, "null argument");
+    return guarded([&] { make_pattern(h->b->sizes_of(mission), iGfun, jGvar); });
 }
 
 int tolfg_batch_set_trajectories(tolfg_batch *h, int B, const tolfg_traj *trajs)
@@ -300,7 +318,7 @@ int tolfg_batch_x0(const tolfg_batch *h, int t, double zi, double *x)
     if (!h || !x) return fail(TOLFG_ERR_ARG, "null argument");
     return guarded([&] {
         const tolfg_traj &tr = h->b->trajectory(t);
-        initial_guess(h->b->sizes(), h->b->airframe(tr.aircraft), Start{tr.xi, tr.yi, zi}, h->b->chi_d(t), x);
+        initial_guess(h->b->sizes_of_traj(t), h->b->airframe(tr.aircraft), Start{tr.xi, tr.yi, zi}, h->b->chi_d(t), x);
     });
 }
 
@@ -322,10 +340,10 @@ int tolfg_batch_bounds(const tolfg_batch *h, int t, double zi, double *xlow, dou
 {
     if (!h) return fail(TOLFG_ERR_ARG, "null batch");
     return guarded([&] {
-        const Sizes &s = h->b->sizes();
+        const Sizes &s = h->b->sizes_of_traj(t);
         const tolfg_traj &tr = h->b->trajectory(t);
         std::vector<double> xl(s.n), xu(s.n), Fl(s.neF), Fu(s.neF);
-        set_limits(s, h->b->airframe(tr.aircraft), h->b->limits(), Start{tr.xi, tr.yi, zi}, xl.data(), xu.data(),
+        set_limits(s, h->b->airframe(tr.aircraft), h->b->limits(s.mission), Start{tr.xi, tr.yi, zi}, xl.data(), xu.data(),
                    Fl.data(), Fu.data());
         if (xlow) std::memcpy(xlow, xl.data(), sizeof(double) * s.n);
         if (xupp) std::memcpy(xupp, xu.data(), sizeof(double) * s.n);
@@ -366,9 +384,8 @@ int tolfg_batch_kernel_time(tolfg_batch *h, double *avg_ms, double *min_ms)
 
 double tolfg_batch_algorithmic_bytes(const tolfg_batch *h, int B)
 {
-    if (!h) return 0.0;
-    const Sizes &s = h->b->sizes();
-    return (double)h->b->elem_size() * (double)B * ((double)s.n + s.neF + s.neG);
+    if (!h || B < 0) return 0.0;
+    return h->b->algorithmic_bytes(B);
 }
 
 }  // extern "C"

@@ -6,7 +6,7 @@
 
 namespace tolfg {
 
-enum { MISSION_S10 = 0, MISSION_G7 = 1 };
+enum { MISSION_S10 = 0, MISSION_G7 = 1, MISSION_MIXED = 2 };   // MIXED: every trajectory carries its own (TrajDev::mission)
 enum { WIND_NONE = 0, WIND_SHEAR = 1, WIND_TABLE = 2, WIND_GRID = 3 };   // kernel-side enumeration
 enum { MAX_AIRCRAFT = 8 };
 enum { PATTERN_REFERENCE = 0, PATTERN_COMPACT = 1 };   // slab_table.h
@@ -35,7 +35,7 @@ struct TrajDev {
     double xg, yg, rg; // goal, NED (src/problem.cpp:24-27)
     double cchi, schi; // cos/sin of G7's chi_d (src/problemG7.cpp:524)
     int    ac;         // index into FgArgs::ac
-    int    pad;
+    int    mission;    // MISSION_S10 | MISSION_G7 of this trajectory (read by MISSION_MIXED launches only)
     double xi, yi, zi; // start position (src/problem.cpp:83-85), for the initial-guess and bounds kernels
     double chi_d;
 };
@@ -57,7 +57,8 @@ struct FgArgs {
     const void    *wind;   // [B][12][N+1] (ENU, reference member order) or nullptr
     GridDev        grid;   // WIND_GRID only
     const TrajDev *traj;   // [B]
-    int  B, N, c0;
+    int  B, N;
+    int  c0[2];            // position in G of node 0's slab, per mission
     int  tiles, nt;        // tiles per trajectory and nodes per tile, from plan_tiles()
     int  needF, needG;
     int  pattern;          // PATTERN_REFERENCE (104-entry slabs) | PATTERN_COMPACT (46-entry slabs)
@@ -69,9 +70,15 @@ struct FgArgs {
     int  xcd_chunk;        // > 0: ceil(B*tiles/8), workgroup id -> tile (id % 8) * xcd_chunk + id / 8; 0: id -> tile id
     double *partial;       // [B*tiles][2] objective partials (sum T^2, sum (r-R)^2), device; on the fused path
                            // every slot is "empty" (kEmptySlotWord) between launches
-    unsigned *counter;     // [B] arrival counters of the fused path: zero before a launch, reset by the finalizing wave
+    unsigned *counter;     // [B + 1] arrival counters of the fused path ([B]: departures, below): zero before a
+                           // launch, reset by the wave that saw the last arrival
+    // Completion word for the SNOPT callback (host-mapped, or nullptr): when every wave's stores are visible
+    // to the host, the last wave to leave writes done_seq there, so the caller can spin on it instead of
+    // synchronising the stream.
+    unsigned long long *done;
+    unsigned long long done_seq;
     void   *obj;           // optional [B]: finalize_kernel also writes the objectives here, contiguous
-    double kT, kp, kv, kdt;
+    double kT[2], kp[2], kv[2], kdt[2];   // gains, per mission (problems/<mission>/gains.param)
     AcCoef ac[MAX_AIRCRAFT];
 #ifdef TOLFG_STAMPS
     // diagnostic build only (tools/fgprobe.cpp): per-wave s_memtime stamps, 8 per workgroup, and a
@@ -84,13 +91,21 @@ struct FgArgs {
 // Tiling of one trajectory's N dynamic nodes: `tiles` tiles of `nt` <= max_nt nodes (the last may be
 // short).  max_nt is a multiple of 4 in [4, 64]; 0 = 64.
 void plan_tiles(int N, int dtype, int max_nt, int *tiles, int *nt);
-// Tile size the host picks for a launch of B trajectories of N nodes (measured)
-int pick_tile_nodes(int B, int N, int dtype, int pattern);
+// Per-launch choices the host makes from the size of the outputs (plan.cpp holds the measurements)
+struct LaunchPlan {
+    int max_nt;            // upper bound on nodes per tile handed to plan_tiles()
+    int waves_per_cu;      // cap on resident tile waves per CU, 0 = none
+    int nt_stores;         // non-temporal slab stream
+    int xcd;               // deal the tiles to the XCDs in contiguous eighths
+};
+LaunchPlan plan_launch(double out_bytes, int dtype, int pattern);
 
-// One evaluation = fg_kernel + finalize_kernel on stream s: F and G of B trajectories.  dtype: 0 = f64, 1 = f32.  vec = elements per
-// 16-byte access the caller has verified alignment for (f64: 2 or 1; f32: 4 or 1).
-// t0/t1 (may be null) are recorded on s immediately around fg_kernel, the dominant kernel.
-hipError_t launch_fg(const FgArgs &a, int mission, int wind, int dtype, int vec, hipStream_t s,
+// One evaluation on stream s: F and G of B trajectories.  dtype: 0 = f64, 1 = f32.  vec = elements per
+// 16-byte access the caller has verified alignment of X, F and the row strides for (f64: 2 or 1;
+// f32: 4 or 1); svec <= vec = elements per slab store the slab regions (G + c0) are aligned for
+// (f32 with c0 % 4 == 2, e.g. G7 at ts = 200: vec 4, svec 2).
+// t0/t1 (may be null) are recorded on s around the whole evaluation.
+hipError_t launch_fg(const FgArgs &a, int mission, int wind, int dtype, int vec, int svec, hipStream_t s,
                      hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
 
 // dObj[t] = F[t*ldf]
@@ -103,9 +118,9 @@ struct BoundsArgs {
     void *xlow, *xupp; long ldx;
     void *Flow, *Fupp; long ldf;
     const TrajDev *traj;
-    int B, N, nb, mission;
-    double dtmin, dtmax;
-    AcBounds ac[MAX_AIRCRAFT];
+    int B, N, mission;     // mission may be MISSION_MIXED; rows of a mixed batch are sized for the larger mission
+    double dtmin[2], dtmax[2];          // per mission (problems/<mission>/limits.param)
+    AcBounds ac[2][MAX_AIRCRAFT];       // [mission][air-frame]
 };
 hipError_t launch_bounds(const BoundsArgs &a, int dtype, hipStream_t s);
 

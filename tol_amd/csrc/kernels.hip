@@ -383,12 +383,13 @@ struct Publish {
 
 // One tile: everything a wavefront does for `cnt` consecutive nodes of trajectory b.  lds is the
 // wave's own TILE*RS-element region; sumT / sumP return the tile's objective terms (wave-uniform).
-template <typename T, int MISSION, int WIND, int VEC, int PAT, bool NT>
+template <typename T, int MISSION, int WIND, int VEC, int SV, int PAT, bool NT>
 __device__ __forceinline__ void tile_body(const FgArgs &a, T *lds, int item, int lane, T &sumT_out, T &sumP_out, Publish &pub)
 {
     typedef typename Vec<T, VEC>::type vec;
-    // slab stores: 16 bytes per lane where the slab length allows (46 floats are 23 pairs, not quads)
-    constexpr int GV = (PAT == PATTERN_COMPACT && VEC == 4) ? 2 : VEC;
+    // slab stores: SV elements per lane (16 bytes where alignment allows), and where the slab length
+    // allows (46 floats are 23 pairs, not quads)
+    constexpr int GV = (PAT == PATTERN_COMPACT && SV == 4) ? 2 : SV;
     constexpr int SLABN = SlabGeom<PAT, GV>::SLABN;
     constexpr int NW = ((NI * TILE + 9 + VEC - 1) / VEC + TILE - 1) / TILE;   // window vectors per lane
     const int N = a.N;
@@ -424,6 +425,8 @@ __device__ __forceinline__ void tile_body(const FgArgs &a, T *lds, int item, int
         }
     }
     const TrajDev tr = a.traj[b];
+    // the trajectory's mission: a template constant, or (mixed batch) wave-uniform from its record
+    const int ms = MISSION == MISSION_MIXED ? __builtin_amdgcn_readfirstlane(tr.mission) : MISSION;
     const T dt = xrow[0];
     __syncthreads();
     TOLFG_STAMP(a, 1);
@@ -465,9 +468,9 @@ __device__ __forceinline__ void tile_body(const FgArgs &a, T *lds, int item, int
     }
 
     // ---- objective terms of this tile's nodes (node N is the finalizing wave's)
-    const T kT = T(a.kT), kp = T(a.kp);
+    const T kT = T(a.kT[ms]), kp = T(a.kp[ms]);
     T sumT = act ? s[10] * s[10] : T(0), sumP = T(0);
-    if constexpr (MISSION == MISSION_S10) {
+    if (ms == MISSION_S10) {
         // src/problemS10.cpp:247-262 (value), :346-375 (gradient)
         const T dx = s[0] - T(tr.xg), dy = s[1] - T(tr.yg);
         const T r = sqrt_t(dx * dx + dy * dy);
@@ -506,7 +509,7 @@ __device__ __forceinline__ void tile_body(const FgArgs &a, T *lds, int item, int
         __builtin_amdgcn_sched_barrier(0);
         SlabOffsets<T, PAT, GV> so;
         so.init(lane);
-        if (!(TOLFG_VARIANT(a) & 2048)) store_slabs<T, PAT, GV, NT>(lds, Grow + a.c0 + (long)SLABN * k0, cnt, lane, so);
+        if (!(TOLFG_VARIANT(a) & 2048)) store_slabs<T, PAT, GV, NT>(lds, Grow + a.c0[ms] + (long)SLABN * k0, cnt, lane, so);
         TOLFG_STAMP(a, 4);
     }
     TOLFG_STAMP(a, 5);
@@ -522,40 +525,45 @@ __device__ __forceinline__ void tile_body(const FgArgs &a, T *lds, int item, int
 // in-order sum over the tiles' objective partials (deterministic, no atomics).
 // sumT / sumP: the objective terms of nodes 0..N-1, already added up in tile order.
 template <typename T, int MISSION, int PAT>
-__device__ __forceinline__ void finalize_body(const FgArgs &a, int b, int lane, T sumT, T sumP)
+__device__ __forceinline__ void finalize_body(const FgArgs &a, int b, int lane, T sumT, T sumP, const T *edge = nullptr)
 {
+    // edge (optional): [dt | node 0's 11 values | node N's 11 values], fetched ahead of time by the caller
+    // (the callback kernel reads x from host memory: one PCIe round trip less on its critical path)
     constexpr int SLABN = PAT == PATTERN_COMPACT ? SLAB_COMPACT : SLAB_FULL;
     const int N = a.N;
     const T *x = static_cast<const T *>(a.X) + (long)b * a.ldx;
     T *F = static_cast<T *>(a.F) + (long)b * a.ldf;
     T *G = static_cast<T *>(a.G) + (long)b * a.ldg;
     const TrajDev tr = a.traj[b];
-    const T dt = x[0];
-    const T kT = T(a.kT), kp = T(a.kp);
-    const T TN = x[NI * N + 11];
-    const long gb = a.c0 + (long)SLABN * N;         // first boundary-row entry
+    const int ms = MISSION == MISSION_MIXED ? __builtin_amdgcn_readfirstlane(tr.mission) : MISSION;
+    auto X0 = [&](int m) { return edge ? edge[1 + m] : x[1 + m]; };               // node 0, m = 0..10
+    auto XN = [&](int m) { return edge ? edge[12 + m] : x[NI * N + 1 + m]; };     // node N
+    const T dt = edge ? edge[0] : x[0];
+    const T kT = T(a.kT[ms]), kp = T(a.kp[ms]);
+    const T TN = XN(10);
+    const long gb = a.c0[ms] + (long)SLABN * N;     // first boundary-row entry
 
     if (a.needF) sumT += TN * TN;
 
-    if constexpr (MISSION == MISSION_S10) {
-        const T dx = x[NI * N + 1] - T(tr.xg), dy = x[NI * N + 2] - T(tr.yg);
+    if (ms == MISSION_S10) {
+        const T dx = XN(0) - T(tr.xg), dy = XN(1) - T(tr.yg);
         const T r = sqrt_t(dx * dx + dy * dy);
         const T d = r - T(tr.rg);
         if (a.needF) {
             sumP += d * d;
             if (lane == 0) {                                                                  // src/problemS10.cpp:264
-                const T obj = T(0.5) * kT * sumT + T(0.5) * kp * sumP + T(a.kdt) * dt;
+                const T obj = T(0.5) * kT * sumT + T(0.5) * kp * sumP + T(a.kdt[ms]) * dt;
                 F[0] = obj;
                 if (a.obj) static_cast<T *>(a.obj)[b] = obj;
             }
             if (lane < 11) {                                                                  // :292-303
-                T v = x[NI * N + 1 + lane] - x[1 + lane];
+                T v = XN(lane) - X0(lane);
                 if (lane == 5) v = v - T(kTwoPi);
                 F[8 * N + 1 + lane] = v;
             }
         }
         if (a.needG) {
-            if (lane == 0) G[0] = T(a.kdt);
+            if (lane == 0) G[0] = T(a.kdt[ms]);
             if (lane < 3) G[1 + 3 * N + lane] = lane == 0 ? kp * d * dx / r : (lane == 1 ? kp * d * dy / r : kT * TN);
             // rows [dt, node 0, node N] = [0, -1, +1]; the dt entry is undefined in the
             // reference (src/problemS10.cpp:397), defined as 0 here and dropped by the compact pattern
@@ -567,13 +575,13 @@ __device__ __forceinline__ void finalize_body(const FgArgs &a, int b, int lane, 
             }
         }
     } else {
-        const T x0 = x[1], y0 = x[2], xf = x[NI * N + 1], yf = x[NI * N + 2];
+        const T x0 = X0(0), y0 = X0(1), xf = XN(0), yf = XN(1);
         const T dxf = xf - x0, dyf = yf - y0;
         const T dist = sqrt_t(dxf * dxf + dyf * dyf);
         const T cchi = T(tr.cchi), schi = T(tr.schi);
         if (a.needF) {
             if (lane == 0) {                                                                  // src/problemG7.cpp:249
-                const T obj = kT * T(0.5) * sumT + T(a.kv) * T(N) * dt / dist;
+                const T obj = kT * T(0.5) * sumT + T(a.kv[ms]) * T(N) * dt / dist;
                 F[0] = obj;
                 if (a.obj) static_cast<T *>(a.obj)[b] = obj;
             }
@@ -584,7 +592,7 @@ __device__ __forceinline__ void finalize_body(const FgArgs &a, int b, int lane, 
                 else if (lane == 11) {
                     const T ex = T(tr.xg) - x0, ey = T(tr.yg) - y0;
                     v = dist - sqrt_t(ex * ex + ey * ey);
-                } else v = x[NI * N + 1 + lane] - x[1 + lane];
+                } else v = XN(lane) - X0(lane);
                 F[8 * N + 1 + lane] = v;
             }
         }
@@ -637,6 +645,26 @@ __device__ __forceinline__ void finalize_body(const FgArgs &a, int b, int lane, 
     }
 }
 
+// Callback completion (a.done): each leaving wave (or workgroup, through `leader`) makes its stores
+// visible at system scope (FENCE; the single-workgroup kernel has done so before its barrier), then
+// adds to the departure counter; the last one resets the counter and writes the completion word the
+// host spins on.  `s_waitcnt vmcnt(0)` instead of the release fence is NOT enough: the host then saw
+// the word before the last stores (F[0] still 0, tests/test_compact_pattern.py on MI355X).
+template <bool FENCE = true>
+__device__ __forceinline__ void signal_done(const FgArgs &a, int participants, bool leader)
+{
+    if constexpr (FENCE) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    if (leader) {
+        unsigned *dep = a.counter + a.B;
+        bool last = true;
+        if (participants > 1) {
+            last = __hip_atomic_fetch_add(dep, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(participants - 1);
+            if (last) __hip_atomic_store(dep, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (last) __hip_atomic_store(a.done, a.done_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 // Sum of a trajectory's tile partials in one fixed order (lane l adds tiles l, l+64, ...; then the
 // butterfly), so the objective does not depend on which wave finalizes or on arrival order.
 // POLL false: plain loads (an earlier launch or this workgroup's LDS wrote them); true: waves of this
@@ -677,7 +705,7 @@ __device__ __forceinline__ void sum_partials(const double *part, int tiles, int 
 // profiles/r02_write_shapes.md); otherwise consecutive workgroups walk the memory in order.
 // Fused form (a.fused): the wave that arrives last at its trajectory's counter also finalizes it, so
 // an evaluation is one launch; otherwise finalize_kernel follows.
-template <typename T, int MISSION, int WIND, int VEC, int PAT, bool NT>
+template <typename T, int MISSION, int WIND, int VEC, int SV, int PAT, bool NT>
 __global__ __launch_bounds__(TILE, TOLFG_MIN_WAVES_PER_SIMD) void fg_kernel(const FgArgs a)
 {
     // dynamic LDS: TILE*RS elements are used; the launch may request more to cap the waves per CU
@@ -696,7 +724,7 @@ __global__ __launch_bounds__(TILE, TOLFG_MIN_WAVES_PER_SIMD) void fg_kernel(cons
         pub.slot = a.partial + 2 * (long)item;
         pub.counter = a.counter + b;
     }
-    tile_body<T, MISSION, WIND, VEC, PAT, NT>(a, reinterpret_cast<T *>(lds_raw), item, lane, sumT, sumP, pub);
+    tile_body<T, MISSION, WIND, VEC, SV, PAT, NT>(a, reinterpret_cast<T *>(lds_raw), item, lane, sumT, sumP, pub);
     if (a.fused) {
         const unsigned old = __builtin_amdgcn_readfirstlane(pub.old);
         if (old == (unsigned)(a.tiles - 1)) {          // wave-uniform: every tile of b has arrived
@@ -709,6 +737,7 @@ __global__ __launch_bounds__(TILE, TOLFG_MIN_WAVES_PER_SIMD) void fg_kernel(cons
         a.partial[2 * (long)item + 0] = (double)sumT;
         a.partial[2 * (long)item + 1] = (double)sumP;
     }
+    if (a.done) signal_done(a, a.B * a.tiles, lane == 0);
 }
 
 template <typename T, int MISSION, int PAT>
@@ -732,15 +761,31 @@ __global__ __launch_bounds__(8 * TILE) void fg_single_kernel(const FgArgs a)
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x / TILE), lane = threadIdx.x % TILE;   // w is wave-uniform: keep it scalar
     const int b = blockIdx.x;
     double *red = reinterpret_cast<double *>(lds + (long)a.tiles * TILE * RS);     // [tiles][2]
+    T *edge = reinterpret_cast<T *>(red + 2 * a.tiles);                            // [24] dt, node 0, node N
+    // wave 0 finalizes: it asks for the values finalize_body reads right away, so that they are back
+    // (x may live in host memory) long before they are needed
+    T pre = T(0);
+    if (w == 0 && lane < 23) {
+        const T *x = static_cast<const T *>(a.X) + (long)b * a.ldx;
+        pre = x[lane <= 11 ? lane : NI * a.N + lane - 11];
+    }
     T sumT, sumP;
     Publish pub{nullptr, nullptr, 0u};
-    tile_body<T, MISSION, WIND, VEC, PAT, false>(a, lds + (long)w * TILE * RS, b * a.tiles + w, lane, sumT, sumP, pub);
+    tile_body<T, MISSION, WIND, VEC, VEC, PAT, false>(a, lds + (long)w * TILE * RS, b * a.tiles + w, lane, sumT, sumP, pub);
     if (lane == 0) { red[2 * w] = (double)sumT; red[2 * w + 1] = (double)sumP; }
+    if (w == 0 && lane < 23) edge[lane] = pre;
     __syncthreads();
     if (w == 0) {
         T st = T(0), sp = T(0);
         if (a.needF) sum_partials<T, false>(red, a.tiles, lane, st, sp);
-        finalize_body<T, MISSION, PAT>(a, b, lane, st, sp);
+        finalize_body<T, MISSION, PAT>(a, b, lane, st, sp, edge);
+    }
+    if (a.done) {
+        // every wave: its stores are visible to the host (system-scope release: acknowledged AND written
+        // back -- an acknowledgement alone was measured not to be enough) before the leader reports
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+        __syncthreads();
+        signal_done<false>(a, a.B, threadIdx.x == 0);
     }
 }
 
@@ -752,34 +797,43 @@ __global__ void objectives_kernel(const T *F, long ldf, T *obj, int B)
 }
 
 template <typename T, int MISSION, int WIND, int PAT>
-hipError_t launch_vec(const FgArgs &a, int vec, dim3 grid, hipStream_t s, hipEvent_t t0, hipEvent_t t1)
+hipError_t launch_vec(const FgArgs &a, int vec, int svec, dim3 grid, hipStream_t s, hipEvent_t t0, hipEvent_t t1)
 {
     constexpr int VMAX = 16 / sizeof(T);
     hipError_t e;
     if (a.single) {
         // one workgroup per trajectory, one launch (the callback path)
-        const unsigned ldsz = (unsigned)(a.tiles * TILE * RS * sizeof(T) + 16 * a.tiles);
-        const dim3 g1(a.B), b1(TILE * a.tiles);
-        if (t0 && (e = hipEventRecord(t0, s)) != hipSuccess) return e;
-        if (vec == VMAX) {
-            auto kf = fg_single_kernel<T, MISSION, WIND, VMAX, PAT>;
-            if (ldsz > 64 * 1024 && (e = hipFuncSetAttribute(reinterpret_cast<const void *>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, ldsz)) != hipSuccess) return e;
-            hipLaunchKernelGGL(kf, g1, b1, ldsz, s, a);
+        if constexpr (MISSION == MISSION_MIXED) {
+            return hipErrorInvalidValue;           // a mixed batch always takes the tile-per-workgroup path
         } else {
-            auto kf = fg_single_kernel<T, MISSION, WIND, 1, PAT>;
-            if (ldsz > 64 * 1024 && (e = hipFuncSetAttribute(reinterpret_cast<const void *>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, ldsz)) != hipSuccess) return e;
-            hipLaunchKernelGGL(kf, g1, b1, ldsz, s, a);
+            const unsigned ldsz = (unsigned)(a.tiles * TILE * RS * sizeof(T) + 16 * a.tiles + 24 * sizeof(T));
+            const dim3 g1(a.B), b1(TILE * a.tiles);
+            if (t0 && (e = hipEventRecord(t0, s)) != hipSuccess) return e;
+            if (vec == VMAX && svec == VMAX) {
+                auto kf = fg_single_kernel<T, MISSION, WIND, VMAX, PAT>;
+                if (ldsz > 64 * 1024 && (e = hipFuncSetAttribute(reinterpret_cast<const void *>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, ldsz)) != hipSuccess) return e;
+                hipLaunchKernelGGL(kf, g1, b1, ldsz, s, a);
+            } else {
+                auto kf = fg_single_kernel<T, MISSION, WIND, 1, PAT>;
+                if (ldsz > 64 * 1024 && (e = hipFuncSetAttribute(reinterpret_cast<const void *>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, ldsz)) != hipSuccess) return e;
+                hipLaunchKernelGGL(kf, g1, b1, ldsz, s, a);
+            }
+            if ((e = hipGetLastError()) != hipSuccess) return e;
+            return t1 ? hipEventRecord(t1, s) : hipSuccess;
         }
-        if ((e = hipGetLastError()) != hipSuccess) return e;
-        return t1 ? hipEventRecord(t1, s) : hipSuccess;
     }
     if (t0 && (e = hipEventRecord(t0, s)) != hipSuccess) return e;
     const unsigned lds = (unsigned)fg_lds_request(sizeof(T) == 8 ? 0 : 1, a.waves_per_cu);
-    if (vec == VMAX) {
-        if (a.nt_stores) hipLaunchKernelGGL((fg_kernel<T, MISSION, WIND, VMAX, PAT, true>), grid, dim3(TILE), lds, s, a);
-        else             hipLaunchKernelGGL((fg_kernel<T, MISSION, WIND, VMAX, PAT, false>), grid, dim3(TILE), lds, s, a);
+    if (vec == VMAX && svec == VMAX) {
+        if (a.nt_stores) hipLaunchKernelGGL((fg_kernel<T, MISSION, WIND, VMAX, VMAX, PAT, true>), grid, dim3(TILE), lds, s, a);
+        else             hipLaunchKernelGGL((fg_kernel<T, MISSION, WIND, VMAX, VMAX, PAT, false>), grid, dim3(TILE), lds, s, a);
+    } else if (VMAX == 4 && vec == VMAX && svec == 2) {
+        // fp32 rows whose slab regions sit on 8-byte boundaries only (c0 % 4 == 2): 16-byte loads, 8-byte slab stores
+        constexpr int SV2 = VMAX == 4 ? 2 : VMAX;
+        if (a.nt_stores) hipLaunchKernelGGL((fg_kernel<T, MISSION, WIND, VMAX, SV2, PAT, true>), grid, dim3(TILE), lds, s, a);
+        else             hipLaunchKernelGGL((fg_kernel<T, MISSION, WIND, VMAX, SV2, PAT, false>), grid, dim3(TILE), lds, s, a);
     } else {
-        hipLaunchKernelGGL((fg_kernel<T, MISSION, WIND, 1, PAT, false>), grid, dim3(TILE), lds, s, a);
+        hipLaunchKernelGGL((fg_kernel<T, MISSION, WIND, 1, 1, PAT, false>), grid, dim3(TILE), lds, s, a);
     }
     e = hipGetLastError();
     if (e != hipSuccess) return e;
@@ -792,23 +846,27 @@ hipError_t launch_vec(const FgArgs &a, int vec, dim3 grid, hipStream_t s, hipEve
 }
 
 template <typename T, int MISSION, int PAT>
-hipError_t launch_wind(const FgArgs &a, int wind, int vec, dim3 grid, hipStream_t s, hipEvent_t t0, hipEvent_t t1)
+hipError_t launch_wind(const FgArgs &a, int wind, int vec, int svec, dim3 grid, hipStream_t s, hipEvent_t t0, hipEvent_t t1)
 {
     switch (wind) {
-    case WIND_NONE:  return launch_vec<T, MISSION, WIND_NONE, PAT>(a, vec, grid, s, t0, t1);
-    case WIND_SHEAR: return launch_vec<T, MISSION, WIND_SHEAR, PAT>(a, vec, grid, s, t0, t1);
-    case WIND_TABLE: return launch_vec<T, MISSION, WIND_TABLE, PAT>(a, vec, grid, s, t0, t1);
-    case WIND_GRID:  return launch_vec<T, MISSION, WIND_GRID, PAT>(a, vec, grid, s, t0, t1);
+    case WIND_NONE:  return launch_vec<T, MISSION, WIND_NONE, PAT>(a, vec, svec, grid, s, t0, t1);
+    case WIND_SHEAR: return launch_vec<T, MISSION, WIND_SHEAR, PAT>(a, vec, svec, grid, s, t0, t1);
+    case WIND_TABLE: return launch_vec<T, MISSION, WIND_TABLE, PAT>(a, vec, svec, grid, s, t0, t1);
+    case WIND_GRID:  return launch_vec<T, MISSION, WIND_GRID, PAT>(a, vec, svec, grid, s, t0, t1);
     }
     return hipErrorInvalidValue;
 }
 
 template <typename T, int PAT>
-hipError_t launch_mission(const FgArgs &a, int mission, int wind, int vec, dim3 grid, hipStream_t s, hipEvent_t t0,
+hipError_t launch_mission(const FgArgs &a, int mission, int wind, int vec, int svec, dim3 grid, hipStream_t s, hipEvent_t t0,
                           hipEvent_t t1)
 {
-    return mission == MISSION_S10 ? launch_wind<T, MISSION_S10, PAT>(a, wind, vec, grid, s, t0, t1)
-                                  : launch_wind<T, MISSION_G7, PAT>(a, wind, vec, grid, s, t0, t1);
+    switch (mission) {
+    case MISSION_S10:   return launch_wind<T, MISSION_S10, PAT>(a, wind, vec, svec, grid, s, t0, t1);
+    case MISSION_G7:    return launch_wind<T, MISSION_G7, PAT>(a, wind, vec, svec, grid, s, t0, t1);
+    case MISSION_MIXED: return launch_wind<T, MISSION_MIXED, PAT>(a, wind, vec, svec, grid, s, t0, t1);
+    }
+    return hipErrorInvalidValue;
 }
 
 
@@ -823,9 +881,9 @@ __global__ void x0_kernel(const FgArgs a)
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= a.B) return;
     constexpr double kRho = 1.2682, kPi = 3.14159265358979323846;
-    const bool loiter = MISSION == MISSION_S10;
     const int N = a.N;
     const TrajDev tr = a.traj[b];
+    const bool loiter = (MISSION == MISSION_MIXED ? tr.mission : MISSION) == MISSION_S10;
     const AcCoef ac = a.ac[tr.ac];
     T *x = static_cast<T *>(const_cast<void *>(a.X)) + (long)b * a.ldx;
     const double tfinal = loiter ? 20.0 : 10.0;
@@ -892,18 +950,19 @@ __global__ void bounds_kernel(const BoundsArgs a)
 {
     const int b = blockIdx.y;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int n = 11 * (a.N + 1) + 1, neF = 8 * a.N + 1 + a.nb;
     const TrajDev tr = a.traj[b];
+    const int ms = a.mission == MISSION_MIXED ? tr.mission : a.mission;
+    const int n = 11 * (a.N + 1) + 1, neF = 8 * a.N + 1 + (ms == MISSION_S10 ? 11 : 12);
     if (i < n) {
         double lo, up;
-        if (i == 0) { lo = a.dtmin; up = a.dtmax; }
+        if (i == 0) { lo = a.dtmin[ms]; up = a.dtmax[ms]; }
         else {
             const int k = (i - 1) / 11, m = (i - 1) % 11;
-            if (k > 0) { lo = a.ac[tr.ac].lo[m]; up = a.ac[tr.ac].up[m]; }
+            if (k > 0) { lo = a.ac[ms][tr.ac].lo[m]; up = a.ac[ms][tr.ac].up[m]; }
             else {
                 // node 0 is pinned to the start with the constants of src/problem.cpp:80-134
                 constexpr double kPi = 3.14159265358979323846;
-                const bool loiter = a.mission == MISSION_S10;
+                const bool loiter = ms == MISSION_S10;
                 switch (m) {
                 case 0: lo = up = tr.xi; break;
                 case 1: lo = up = tr.yi; break;
@@ -925,7 +984,7 @@ __global__ void bounds_kernel(const BoundsArgs a)
     if (i < neF) {
         double lo = 0.0, up = 0.0;
         if (i == 0) { lo = -1e20; up = 1e20; }
-        else if (a.mission == MISSION_G7 && i == neF - 1) lo = -1e20;     // dist <= dmax
+        else if (ms == MISSION_G7 && i == neF - 1) lo = -1e20;     // dist <= dmax
         static_cast<T *>(a.Flow)[(long)b * a.ldf + i] = T(lo);
         static_cast<T *>(a.Fupp)[(long)b * a.ldf + i] = T(up);
     }
@@ -933,24 +992,25 @@ __global__ void bounds_kernel(const BoundsArgs a)
 
 }  // namespace
 
-hipError_t launch_fg(const FgArgs &a, int mission, int wind, int dtype, int vec, hipStream_t s, hipEvent_t t0,
+hipError_t launch_fg(const FgArgs &a, int mission, int wind, int dtype, int vec, int svec, hipStream_t s, hipEvent_t t0,
                      hipEvent_t t1)
 {
     if (a.B <= 0) return hipSuccess;
     // the tiling must be one plan_tiles() can produce: nt a multiple of 4 in [4, 64], tiles = ceil(N/nt)
     if (a.N < 1 || a.nt < 4 || a.nt > TILE || (a.nt & 3) || a.tiles != (a.N + a.nt - 1) / a.nt || !a.partial)
         return hipErrorInvalidValue;
-    if (a.fused && !a.single && !a.counter) return hipErrorInvalidValue;
+    if ((a.fused || a.done) && !a.counter) return hipErrorInvalidValue;
+    if (a.done && !a.fused && !a.single) return hipErrorInvalidValue;     // finalize_kernel would still be running
     const long W = (long)a.B * a.tiles;
     if (W > 0x7ffffff0L) return hipErrorInvalidValue;
     if (a.xcd_chunk != 0 && a.xcd_chunk != (int)((W + 7) / 8)) return hipErrorInvalidValue;
     const dim3 grid((unsigned)(a.xcd_chunk > 0 ? 8L * a.xcd_chunk : W));
     if (a.pattern == PATTERN_COMPACT) {
-        return dtype == 0 ? launch_mission<double, PATTERN_COMPACT>(a, mission, wind, vec, grid, s, t0, t1)
-                          : launch_mission<float, PATTERN_COMPACT>(a, mission, wind, vec, grid, s, t0, t1);
+        return dtype == 0 ? launch_mission<double, PATTERN_COMPACT>(a, mission, wind, vec, svec, grid, s, t0, t1)
+                          : launch_mission<float, PATTERN_COMPACT>(a, mission, wind, vec, svec, grid, s, t0, t1);
     }
-    return dtype == 0 ? launch_mission<double, PATTERN_REFERENCE>(a, mission, wind, vec, grid, s, t0, t1)
-                      : launch_mission<float, PATTERN_REFERENCE>(a, mission, wind, vec, grid, s, t0, t1);
+    return dtype == 0 ? launch_mission<double, PATTERN_REFERENCE>(a, mission, wind, vec, svec, grid, s, t0, t1)
+                      : launch_mission<float, PATTERN_REFERENCE>(a, mission, wind, vec, svec, grid, s, t0, t1);
 }
 
 hipError_t launch_objectives(const void *F, long ldf, void *obj, int B, int dtype, hipStream_t s)
@@ -971,11 +1031,13 @@ hipError_t launch_x0(const FgArgs &a, int mission, int dtype, hipStream_t s)
     if (a.B <= 0) return hipSuccess;
     const dim3 grid((a.B + 63) / 64), block(64);
     if (dtype == 0) {
-        if (mission == MISSION_S10) hipLaunchKernelGGL((x0_kernel<double, MISSION_S10>), grid, block, 0, s, a);
-        else                        hipLaunchKernelGGL((x0_kernel<double, MISSION_G7>), grid, block, 0, s, a);
+        if (mission == MISSION_S10)     hipLaunchKernelGGL((x0_kernel<double, MISSION_S10>), grid, block, 0, s, a);
+        else if (mission == MISSION_G7) hipLaunchKernelGGL((x0_kernel<double, MISSION_G7>), grid, block, 0, s, a);
+        else                            hipLaunchKernelGGL((x0_kernel<double, MISSION_MIXED>), grid, block, 0, s, a);
     } else {
-        if (mission == MISSION_S10) hipLaunchKernelGGL((x0_kernel<float, MISSION_S10>), grid, block, 0, s, a);
-        else                        hipLaunchKernelGGL((x0_kernel<float, MISSION_G7>), grid, block, 0, s, a);
+        if (mission == MISSION_S10)     hipLaunchKernelGGL((x0_kernel<float, MISSION_S10>), grid, block, 0, s, a);
+        else if (mission == MISSION_G7) hipLaunchKernelGGL((x0_kernel<float, MISSION_G7>), grid, block, 0, s, a);
+        else                            hipLaunchKernelGGL((x0_kernel<float, MISSION_MIXED>), grid, block, 0, s, a);
     }
     return hipGetLastError();
 }

@@ -5,7 +5,7 @@
 namespace tolfg {
 
 namespace {
-constexpr int TILE = 64;           // nodes per dynamics tile = wavefront width (kernels.hip)
+constexpr int kTileNodes = 64;     // nodes per dynamics tile = wavefront width (kTileNodes in kernels.hip)
 }
 
 void plan_tiles(int N, int dtype, int max_nt, int *tiles, int *nt)
@@ -13,8 +13,8 @@ void plan_tiles(int N, int dtype, int max_nt, int *tiles, int *nt)
     // ceil(N/max_nt) tiles of equal size, the size rounded up to 4 nodes so that every tile's x window
     // (11*k0 elements into the row) starts on a 16-byte boundary for both element sizes
     (void)dtype;
-    int cap = max_nt <= 0 ? TILE : max_nt;
-    cap = (cap < 4 ? 4 : (cap > TILE ? TILE : cap)) & ~3;
+    int cap = max_nt <= 0 ? kTileNodes : max_nt;
+    cap = (cap < 4 ? 4 : (cap > kTileNodes ? kTileNodes : cap)) & ~3;
     const int t = (N + cap - 1) / cap;
     int per = (N + t - 1) / t;
     per = (per + 3) & ~3;
@@ -23,10 +23,27 @@ void plan_tiles(int N, int dtype, int max_nt, int *tiles, int *nt)
     *tiles = (N + per - 1) / per;
 }
 
-int pick_tile_nodes(int B, int N, int dtype, int pattern)
+LaunchPlan plan_launch(double out_bytes, int dtype, int pattern)
 {
-    (void)B; (void)N; (void)dtype; (void)pattern;
-    return TILE;
+    // Measured on MI355X with tools/fgbench.cpp (profiles/r02_tile_fused_sweep.md, r02_write_shapes.md):
+    //  * tile size: lane-per-node tiles smaller than the wavefront lose -- the node arithmetic costs the
+    //    same ~5000 cycles per wave whatever the number of active lanes (32 nodes: equal at best;
+    //    16 nodes: 47-53 % of peak; 8 nodes: 33 %) -- so every shape uses the largest equal tiles <= 64.
+    //  * outputs beyond the 256 MiB Infinity Cache (F+G > 192 MiB: B >= ~1100 at ts=200, fp64): the slab
+    //    stream is non-temporal (plain: -7...-19 %) and the CU is capped at 8 (fp64) or 12 (fp32)
+    //    resident tile waves -- fewer concurrent store streams suit the HBM write path (fp64, B=4096:
+    //    cap 6 / 7 / 8 / 9 / none -> 173.9 / 166.3 / 162.2 / 163.5 / 160.6-163.8 us; fp32 8 / 12 -> 92.4 / 90.8).
+    //  * outputs that fit the cache: plain stores stay on-die (B=1024: 42.6 vs 51.5 us non-temporal,
+    //    B=512: 23.8 vs 31.1 us) and want every wave that fits, so no cap.
+    //  * tiles are dealt to the XCDs in contiguous eighths (+1...+8 %, never slower).
+    LaunchPlan p{};
+    const bool beyond_cache = out_bytes > 192.0 * 1024 * 1024;
+    p.max_nt = kTileNodes;
+    p.nt_stores = beyond_cache ? 1 : 0;
+    p.waves_per_cu = beyond_cache ? (dtype == 0 ? 8 : 12) : 0;
+    (void)pattern;
+    p.xcd = 1;
+    return p;
 }
 
 }  // namespace tolfg

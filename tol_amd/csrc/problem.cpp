@@ -26,6 +26,13 @@ void check(hipError_t e, const char *what)
         throw hip_failure(std::string(what) + ": " + hipGetErrorString(e));
 }
 
+// Drop error codes left behind by calls whose failure was handled (a bounded loop: without a device
+// the runtime reports its absence for ever).
+void clear_errors()
+{
+    for (int i = 0; i < 4 && hipGetLastError() != hipSuccess; ++i) {}
+}
+
 int kernel_wind(int windmodel)
 {
     switch (windmodel) {
@@ -39,10 +46,11 @@ int kernel_wind(int windmodel)
 
 }  // namespace
 
-int mission_from_name(const std::string &name)
+int mission_from_name(const std::string &name, bool allow_mixed)
 {
     if (name == "S10") return MISSION_S10;
     if (name == "G7") return MISSION_G7;
+    if (allow_mixed && (name == "mixed" || name == "S10+G7" || name == "G7+S10")) return MISSION_MIXED;
     throw std::invalid_argument("Mission code \"" + name + "\" not recognized.");   // ref: src/tol.cpp:21
 }
 
@@ -66,39 +74,49 @@ std::string default_root()
 
 batch::batch(const std::string &mission, const std::string &root, const std::vector<std::string> &names,
              int ts, int windmodel, int dtype, int device, int pattern)
-    : gn_(mission, root), lm_(mission, root), sn_(mission, root), windmodel_(windmodel), dtype_(dtype),
-      device_(device)
+    : windmodel_(windmodel), dtype_(dtype), device_(device)
 {
-    const int mid = mission_from_name(mission);
+    mission_ = mission_from_name(mission, true);
     if (names.empty() || names.size() > MAX_AIRCRAFT) throw std::invalid_argument("1..8 aircraft per batch");
     if (dtype != TOLFG_F64 && dtype != TOLFG_F32) throw std::invalid_argument("dtype");
     kernel_wind(windmodel);
     for (const std::string &nm : names) acs_.emplace_back(nm, root);
-    const int N = ts > 0 ? ts : sn_.ts;
+    const char *mname[2] = {"S10", "G7"};
+    for (int m = 0; m < 2; ++m) {
+        if (mission_ != MISSION_MIXED && m != mission_) continue;
+        gn_.emplace_back(mname[m], root); lm_.emplace_back(mname[m], root); sn_.emplace_back(mname[m], root);
+        const snopt &sn = sn_.back();
+        if (sn.numinp != 11 || sn.numstates != 8 || sn.numbounds != (m == MISSION_S10 ? 11 : 12))
+            throw std::invalid_argument(std::string("snopt.param: numinp/numstates/numbounds do not describe ") + mname[m]);
+    }
+    const int N = ts > 0 ? ts : sn_.front().ts;        // a mixed batch shares ts (S10's snopt.param when not given)
     if (N < 1) throw std::invalid_argument("ts must be >= 1");
-    if (sn_.numinp != 11 || sn_.numstates != 8 || sn_.numbounds != (mid == MISSION_S10 ? 11 : 12))
-        throw std::invalid_argument("snopt.param: numinp/numstates/numbounds do not describe " + mission);
     if (pattern != PATTERN_REFERENCE && pattern != PATTERN_COMPACT) throw std::invalid_argument("pattern");
-    sz_ = make_sizes(mid, N, pattern);
+    for (int m = 0; m < 2; ++m) szm_[m] = make_sizes(m, N, pattern);
+    if (mission_ == MISSION_MIXED) {
+        sz_ = szm_[MISSION_S10];
+        sz_.mission = MISSION_MIXED;
+        sz_.nb = std::max(szm_[0].nb, szm_[1].nb);
+        sz_.neF = std::max(szm_[0].neF, szm_[1].neF);
+        sz_.neG = std::max(szm_[0].neG, szm_[1].neG);
+    } else {
+        sz_ = szm_[mission_];
+    }
 
     args_.pattern = pattern;
-    // Resident tile waves per CU (a launch-time LDS request caps it).  Fewer concurrent store streams
-    // suit the HBM write path, too few leave it idle.  Measured with bench.py on MI355X, B = 4096,
-    // ts = 200 (tools/occ_probe.sh): fp64 reference pattern, cap none(9) / 7 / 6 / 5 ->
-    // 5.13 / 5.57 / 5.63 / 5.53 TB/s; compact pattern none / 8 / 6 / 4 -> 5.32 / 5.48 / 4.94 / 4.45;
-    // fp32 none(16) / 12 / 8 / 6 -> 4.73 / 4.81 / 4.90 / 4.47.  TOLFG_WAVES_PER_CU overrides.
-    // With the inputs read from HBM each step (bench.py --x-buffers 4): 5 / 6 / 7 / 8 / none ->
-    // 4.96 / 5.13 / 5.20 / 5.10 / 5.01 TB/s, so 7.
-    waves_per_cu_ = (dtype == TOLFG_F64 && pattern == PATTERN_REFERENCE) ? 7 : 8;
+    // measurement overrides of the launch plan (plan.cpp)
     if (const char *e = std::getenv("TOLFG_WAVES_PER_CU")) { waves_per_cu_ = std::atoi(e); waves_forced_ = true; }
     args_.N = N;
     plan_tiles(N, dtype, 0, &args_.tiles, &args_.nt);      // eval() re-plans for its batch size
     if (const char *e = std::getenv("TOLFG_TILE_NODES")) tile_nodes_forced_ = std::atoi(e);
     if (const char *e = std::getenv("TOLFG_FUSED")) fused_ = std::atoi(e) != 0;
     if (const char *e = std::getenv("TOLFG_NT_STORES")) nt_forced_ = std::atoi(e) != 0;
-    if (const char *e = std::getenv("TOLFG_XCD")) xcd_ = std::atoi(e) != 0;
-    args_.c0 = sz_.c0;
-    args_.kT = gn_.kT; args_.kp = gn_.kp; args_.kv = gn_.kv; args_.kdt = gn_.kdt;
+    if (const char *e = std::getenv("TOLFG_XCD")) xcd_forced_ = std::atoi(e) != 0;
+    for (int m = 0; m < 2; ++m) {
+        const gain &g = gains(m);
+        args_.c0[m] = szm_[m].c0;
+        args_.kT[m] = g.kT; args_.kp[m] = g.kp; args_.kv[m] = g.kv; args_.kdt[m] = g.kdt;
+    }
     for (size_t i = 0; i < acs_.size(); ++i) {
         const aircraft &a = acs_[i];
         args_.ac[i].inv_m = 1.0 / a.mm;
@@ -107,6 +125,28 @@ batch::batch(const std::string &mission, const std::string &root, const std::vec
         args_.ac[i].kind = 1.0 / (a.AR * M_PI * a.ee);
         args_.ac[i].mm = a.mm; args_.ac[i].SS = a.SS; args_.ac[i].AR = a.AR; args_.ac[i].ee = a.ee;
     }
+}
+
+const Sizes &batch::sizes_of(int mission) const
+{
+    if (mission != MISSION_S10 && mission != MISSION_G7) throw std::invalid_argument("mission id");
+    if (mission_ != MISSION_MIXED && mission != mission_) throw std::invalid_argument("this batch holds one mission only");
+    return szm_[mission];
+}
+
+int batch::mission_of_traj(int t) const
+{
+    return mission_ == MISSION_MIXED ? host_traj_.at(t).mission : mission_;
+}
+
+double batch::algorithmic_bytes(int B) const
+{
+    double elems = 0;
+    for (int t = 0; t < B; ++t) {
+        const Sizes &z = (mission_ == MISSION_MIXED && t < ntraj_) ? szm_[host_traj_[t].mission] : (mission_ == MISSION_MIXED ? szm_[0] : sz_);
+        elems += (double)z.n + z.neF + z.neG;
+    }
+    return elems * (double)elem_size();
 }
 
 batch::~batch()
@@ -133,11 +173,32 @@ void batch::set_wind_grid(const tolfg_wind_grid &g)
         std::vector<float> tmp(g.v, g.v + cnt);
         check(hipMemcpy(d_grid_, tmp.data(), sizeof(float) * cnt, hipMemcpyHostToDevice), "hipMemcpy(grid)");
     }
+    grid_host_.assign(g.v, g.v + cnt);      // for the opt-in Woutput.txt dump (problem::dump_wind)
     GridDev &d = args_.grid;
     d.v = d_grid_; d.nx = g.nx; d.ny = g.ny; d.nz = g.nz; d.pad = 0;
     d.x0 = g.x0; d.y0 = g.y0; d.z0 = g.z0; d.dx = g.dx; d.dy = g.dy; d.dz = g.dz;
     d.e0 = g.east_from_datum; d.n0 = g.north_from_datum; d.u0 = g.up_from_datum;
     windmodel_ = TOLFG_WIND_GRID;
+}
+
+bool batch::grid_wind_host(double pn, double pe, double pd, double *v, double *dve, double *dvn, double *dvu) const
+{
+    // the kernel's NodeCtx::grid_wind in host doubles (ref: src/problem.cpp:551-692)
+    if (grid_host_.empty()) return false;
+    const GridDev &gr = args_.grid;
+    const double xs = pe + gr.e0, ys = pn + gr.n0, zs = -pd + gr.u0;
+    auto cell = [](double s, double o, double d, int n) { return std::min(std::max((int)std::floor((s - o) / d), 0), n - 2); };
+    const int xi = cell(xs, gr.x0, gr.dx, gr.nx), yi = cell(ys, gr.y0, gr.dy, gr.ny), zi = cell(zs, gr.z0, gr.dz, gr.nz);
+    const double *g = grid_host_.data() + ((long)xi * gr.ny + yi) * gr.nz + zi;
+    const long sx = (long)gr.ny * gr.nz, sy = gr.nz;
+    const double c[8] = {g[0], g[sx], g[sy], g[sx + sy], g[1], g[sx + 1], g[sy + 1], g[sx + sy + 1]};
+    const double ze = (xs - (gr.x0 + xi * gr.dx)) / gr.dx, et = (ys - (gr.y0 + yi * gr.dy)) / gr.dy, mu = (zs - (gr.z0 + zi * gr.dz)) / gr.dz;
+    const double a = 1 - ze, b = 1 - et, m = 1 - mu;
+    *v = a * b * m * c[0] + ze * b * m * c[1] + a * et * m * c[2] + ze * et * m * c[3] + a * b * mu * c[4] + ze * b * mu * c[5] + a * et * mu * c[6] + ze * et * mu * c[7];
+    *dve = ((c[1] - c[0]) * b * m + (c[3] - c[2]) * et * m + (c[5] - c[4]) * b * mu + (c[7] - c[6]) * et * mu) / gr.dx;
+    *dvn = ((c[2] - c[0]) * a * m + (c[3] - c[1]) * ze * m + (c[6] - c[4]) * a * mu + (c[7] - c[5]) * ze * mu) / gr.dy;
+    *dvu = ((c[4] - c[0]) * a * b + (c[5] - c[1]) * ze * b + (c[6] - c[2]) * a * et + (c[7] - c[3]) * ze * et) / gr.dz;
+    return true;
 }
 
 double batch::chi_d(int t) const
@@ -153,12 +214,15 @@ void batch::set_trajectories(int B, const tolfg_traj *trajs)
     for (int t = 0; t < B; ++t) {
         const tolfg_traj &tr = trajs[t];
         if (tr.aircraft < 0 || tr.aircraft >= (int)acs_.size()) throw std::invalid_argument("aircraft index");
+        if (mission_ == MISSION_MIXED && tr.mission != MISSION_S10 && tr.mission != MISSION_G7)
+            throw std::invalid_argument("trajectory mission must be 0 (S10) or 1 (G7) in a mixed batch");
         TrajDev &d = dev[t];
         d.shear = tr.Vref / tr.href;
         d.xg = tr.north_goal; d.yg = tr.east_goal; d.rg = tr.radius_goal;   // ENU -> NED
         const double cd = std::atan2(tr.east_goal - tr.yi, tr.north_goal - tr.xi);
         d.cchi = std::cos(cd); d.schi = std::sin(cd);
-        d.ac = tr.aircraft; d.pad = 0;
+        d.ac = tr.aircraft;
+        d.mission = mission_ == MISSION_MIXED ? tr.mission : mission_;
         d.xi = tr.xi; d.yi = tr.yi; d.zi = tr.zi; d.chi_d = cd;
     }
     host_traj_.assign(trajs, trajs + B);
@@ -182,7 +246,8 @@ void batch::upload()
 }
 
 void batch::eval(int B, const void *dX, long ldx, void *dF, long ldf, void *dG, long ldg, const void *dWind,
-                 int needF, int needG, hipStream_t stream, void *dObj)
+                 int needF, int needG, hipStream_t stream, void *dObj, unsigned long long *done,
+                 unsigned long long done_seq)
 {
     if (B < 1 || B > ntraj_) throw std::invalid_argument("eval: B exceeds the described trajectories");
     if (!dX || (needF && !dF) || (needG && !dG)) throw std::invalid_argument("eval: null device pointer");
@@ -196,9 +261,10 @@ void batch::eval(int B, const void *dX, long ldx, void *dF, long ldf, void *dG, 
     // workgroup (measured per call: ts=100 24.7 vs 29.2 us, ts=200 29.7 vs 33.1 us; at ts=500, 8 waves
     // per workgroup, the tile-per-workgroup path is as fast, so the single form is used up to ts = 256)
     static const bool no_single = std::getenv("TOLFG_NO_SINGLE_LAUNCH") != nullptr;
-    a.single = (!no_single && B <= 8 && a.N <= 256) ? 1 : 0;
-    plan_tiles(a.N, dtype_, a.single ? 0 : (tile_nodes_forced_ > 0 ? tile_nodes_forced_ : pick_tile_nodes(B, a.N, dtype_, a.pattern)),
-               &a.tiles, &a.nt);
+    a.single = (!no_single && B <= 8 && a.N <= 256 && mission_ != MISSION_MIXED) ? 1 : 0;
+    const double out_bytes = (double)elem_size() * B * ((needF ? sz_.neF : 0) + (needG ? sz_.neG : 0));
+    const LaunchPlan lp = plan_launch(out_bytes, dtype_, a.pattern);
+    plan_tiles(a.N, dtype_, a.single ? 0 : (tile_nodes_forced_ > 0 ? tile_nodes_forced_ : lp.max_nt), &a.tiles, &a.nt);
     const long W = (long)B * a.tiles;
     if (W > partial_cap_) {        // objective partials, 2 doubles per tile
         check(hipSetDevice(device_), "hipSetDevice");
@@ -209,35 +275,36 @@ void batch::eval(int B, const void *dX, long ldx, void *dF, long ldf, void *dG, 
         check(hipMemsetD32(reinterpret_cast<hipDeviceptr_t>(d_partial_), kEmptySlotWord, 4 * (size_t)W), "hipMemsetD32(partial)");
         partial_cap_ = W;
     }
-    if (B > counter_cap_) {        // arrival counters of the fused path: zero between launches
+    if (B > counter_cap_) {        // arrival counters of the fused path (+1: departures): zero between launches
         check(hipSetDevice(device_), "hipSetDevice");
         if (d_counter_) check(hipFree(d_counter_), "hipFree");
         d_counter_ = nullptr;
-        check(hipMalloc(reinterpret_cast<void **>(&d_counter_), sizeof(unsigned) * (size_t)B), "hipMalloc(counter)");
-        check(hipMemset(d_counter_, 0, sizeof(unsigned) * (size_t)B), "hipMemset(counter)");
+        check(hipMalloc(reinterpret_cast<void **>(&d_counter_), sizeof(unsigned) * ((size_t)B + 1)), "hipMalloc(counter)");
+        check(hipMemset(d_counter_, 0, sizeof(unsigned) * ((size_t)B + 1)), "hipMemset(counter)");
         counter_cap_ = B;
     }
     a.partial = d_partial_;
     a.counter = d_counter_;
-    a.fused = fused_ ? 1 : 0;
+    a.fused = (fused_ || done) ? 1 : 0;          // a completion word needs the single-launch form
     a.obj = dObj;
-    // The cap pays only when the output stream really goes to HBM; a batch whose F and G fit the
-    // 256 MiB Infinity Cache is served on-die and wants every wave it can get (B = 1024, ts = 200:
-    // 4.3 TB/s capped, 5.5 TB/s uncapped).
-    const double out_bytes = (double)elem_size() * B * ((needF ? sz_.neF : 0) + (needG ? sz_.neG : 0));
-    const bool beyond_cache = out_bytes > 192.0 * 1024 * 1024;
-    a.waves_per_cu = (waves_forced_ || beyond_cache) ? waves_per_cu_ : 0;
-    a.nt_stores = nt_forced_ >= 0 ? nt_forced_ : (beyond_cache ? 1 : 0);
-    a.xcd_chunk = (xcd_ && !a.single) ? (int)((W + 7) / 8) : 0;
+    a.done = done; a.done_seq = done_seq;
+    a.waves_per_cu = waves_forced_ ? waves_per_cu_ : lp.waves_per_cu;
+    a.nt_stores = nt_forced_ >= 0 ? nt_forced_ : lp.nt_stores;
+    a.xcd_chunk = ((xcd_forced_ >= 0 ? xcd_forced_ : lp.xcd) && !a.single) ? (int)((W + 7) / 8) : 0;
     a.X = dX; a.ldx = ldx; a.F = dF; a.ldf = ldf; a.G = dG; a.ldg = ldg;
     a.wind = dWind; a.traj = d_traj_;
     a.B = B; a.needF = needF ? 1 : 0; a.needG = needG ? 1 : 0;
-    // 16-byte accesses need every row's x window and slab region on a 16-byte boundary
+    // 16-byte accesses need every row's x window on a 16-byte boundary; the slab stores are as wide as
+    // every slab region's alignment allows (c0 of every mission in the batch)
     const int vmax = dtype_ == TOLFG_F64 ? 2 : 4;
     const bool aligned = (reinterpret_cast<uintptr_t>(dX) % 16 == 0) && (ldx % vmax == 0) &&
                          (!needF || ((reinterpret_cast<uintptr_t>(dF) % 16 == 0) && (ldf % vmax == 0))) &&
-                         (!needG || ((reinterpret_cast<uintptr_t>(dG) % 16 == 0) && (ldg % vmax == 0) &&
-                                     (sz_.c0 % vmax == 0)));
+                         (!needG || ((reinterpret_cast<uintptr_t>(dG) % 16 == 0) && (ldg % vmax == 0)));
+    int vec = aligned ? vmax : 1, svec = vec;
+    for (int m = 0; m < 2; ++m)
+        if (mission_ == MISSION_MIXED || m == mission_)
+            while (svec > 1 && szm_[m].c0 % svec != 0) svec >>= 1;
+    if (svec != vec && !(dtype_ == TOLFG_F32 && vec == 4 && svec == 2 && !a.single)) vec = svec = 1;   // the kernel pairs that exist
     hipEvent_t t0 = nullptr, t1 = nullptr;
     if (timing_) {                 // HIP events on the launch stream, around the whole evaluation
         if (ev_used_ + 2 > ev_.size()) {
@@ -248,7 +315,7 @@ void batch::eval(int B, const void *dX, long ldx, void *dF, long ldf, void *dG, 
         t0 = ev_[ev_used_++];
         t1 = ev_[ev_used_++];
     }
-    check(launch_fg(a, sz_.mission, kernel_wind(windmodel_), dtype_, aligned ? vmax : 1, stream, t0, t1), "launch fg");
+    check(launch_fg(a, mission_, kernel_wind(windmodel_), dtype_, vec, svec, stream, t0, t1), "launch fg");
 }
 
 void batch::set_timing(bool on)
@@ -280,7 +347,7 @@ void batch::x0_device(int B, void *dX, long ldx, hipStream_t stream)
     if (!uploaded_) upload();
     FgArgs a = args_;
     a.X = dX; a.ldx = ldx; a.traj = d_traj_; a.B = B;
-    check(launch_x0(a, sz_.mission, dtype_, stream), "launch x0");
+    check(launch_x0(a, mission_, dtype_, stream), "launch x0");
 }
 
 void batch::bounds_device(int B, void *dXlow, void *dXupp, long ldx, void *dFlow, void *dFupp, long ldf, hipStream_t stream)
@@ -290,13 +357,16 @@ void batch::bounds_device(int B, void *dXlow, void *dXupp, long ldx, void *dFlow
     if (!uploaded_) upload();
     BoundsArgs a{};
     a.xlow = dXlow; a.xupp = dXupp; a.ldx = ldx; a.Flow = dFlow; a.Fupp = dFupp; a.ldf = ldf;
-    a.traj = d_traj_; a.B = B; a.N = sz_.N; a.nb = sz_.nb; a.mission = sz_.mission;
-    a.dtmin = lm_.dtmin; a.dtmax = lm_.dtmax;
-    for (size_t i = 0; i < acs_.size(); ++i) {      // src/problem.cpp:272-285
-        const aircraft &c = acs_[i];
-        const double lo[11] = {lm_.xmin, lm_.ymin, lm_.zmin, c.Vamin, -c.gammamax, -1e20, -c.phimax, c.CLmin, -c.phidotmax, -c.phidotmax, c.Tmin};
-        const double up[11] = {lm_.xmax, lm_.ymax, lm_.zmax, c.Vamax, c.gammamax, 1e20, c.phimax, c.CLmax, c.phidotmax, c.phidotmax, c.Tmax};
-        for (int m = 0; m < 11; ++m) { a.ac[i].lo[m] = lo[m]; a.ac[i].up[m] = up[m]; }
+    a.traj = d_traj_; a.B = B; a.N = sz_.N; a.mission = mission_;
+    for (int ms = 0; ms < 2; ++ms) {
+        const limit &lm = limits(ms);
+        a.dtmin[ms] = lm.dtmin; a.dtmax[ms] = lm.dtmax;
+        for (size_t i = 0; i < acs_.size(); ++i) {      // src/problem.cpp:272-285
+            const aircraft &c = acs_[i];
+            const double lo[11] = {lm.xmin, lm.ymin, lm.zmin, c.Vamin, -c.gammamax, -1e20, -c.phimax, c.CLmin, -c.phidotmax, -c.phidotmax, c.Tmin};
+            const double up[11] = {lm.xmax, lm.ymax, lm.zmax, c.Vamax, c.gammamax, 1e20, c.phimax, c.CLmax, c.phidotmax, c.phidotmax, c.Tmax};
+            for (int m = 0; m < 11; ++m) { a.ac[ms][i].lo[m] = lo[m]; a.ac[ms][i].up[m] = up[m]; }
+        }
     }
     check(launch_bounds(a, dtype_, stream), "launch bounds");
 }
@@ -356,11 +426,17 @@ void problem::ensure_device()
     if (const char *e = std::getenv("TOLFG_CALLBACK_STAGING")) zero_copy_ = !(e[0] == '1');
     if (const char *e = std::getenv("TOLFG_ZERO_COPY_LIMIT")) zero_copy_limit_ = (size_t)std::atol(e);
     if (const char *e = std::getenv("TOLFG_CHUNKS")) nchunks_ = std::min(kChunks, std::max(1, std::atoi(e)));
+    if (std::getenv("TOLFG_NO_REGISTER")) register_user_ = false;
+    if (std::getenv("TOLFG_NO_FLAG")) use_flag_ = false;
     check(hipSetDevice(eng_->device()), "hipSetDevice");
     if (!stream_) check(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking), "hipStreamCreate");
     if (!hx_) check(hipHostMalloc(reinterpret_cast<void **>(&hx_), sizeof(double) * ldx_, hipHostMallocDefault), "hipHostMalloc");
     if (!hF_) check(hipHostMalloc(reinterpret_cast<void **>(&hF_), sizeof(double) * ldf_, hipHostMallocDefault), "hipHostMalloc");
     if (!hG_) check(hipHostMalloc(reinterpret_cast<void **>(&hG_), sizeof(double) * ldg_, hipHostMallocDefault), "hipHostMalloc");
+    if (!done_) {
+        check(hipHostMalloc(reinterpret_cast<void **>(&done_), 64, hipHostMallocDefault), "hipHostMalloc");
+        *done_ = 0;
+    }
     if (!dX_) check(hipMalloc(reinterpret_cast<void **>(&dX_), sizeof(double) * ldx_), "hipMalloc");
     if (!dF_) check(hipMalloc(reinterpret_cast<void **>(&dF_), sizeof(double) * ldf_), "hipMalloc");
     if (!dG_) check(hipMalloc(reinterpret_cast<void **>(&dG_), sizeof(double) * ldg_), "hipMalloc");
@@ -376,6 +452,9 @@ problem::~problem()
     if (hx_) (void)hipHostFree(hx_);
     if (hF_) (void)hipHostFree(hF_);
     if (hG_) (void)hipHostFree(hG_);
+    if (done_) (void)hipHostFree(done_);
+    for (const HostView &v : views_) if (v.dev) (void)hipHostUnregister(v.base);
+    clear_errors();
     if (dX_) (void)hipFree(dX_);
     if (dF_) (void)hipFree(dF_);
     if (dG_) (void)hipFree(dG_);
@@ -392,6 +471,7 @@ void problem::set_wind_table(const double *wind_enu)
     check(hipSetDevice(eng_->device()), "hipSetDevice");
     if (!dW_) check(hipMalloc(reinterpret_cast<void **>(&dW_), bytes), "hipMalloc(wind)");
     check(hipMemcpy(dW_, wind_enu, bytes, hipMemcpyHostToDevice), "hipMemcpy(wind)");
+    wind_host_.assign(wind_enu, wind_enu + 12 * (size_t)(eng_->sizes().N + 1));
     eng_->set_windmodel(TOLFG_WIND_TABLE);
     staged_ = false;
 }
@@ -402,25 +482,63 @@ void problem::set_wind_grid(const tolfg_wind_grid &g)
     staged_ = false;
 }
 
-void problem::stage_and_launch(const double xin[], bool needF, bool needG)
+void *problem::device_view(void *p, size_t bytes)
+{
+    if (!register_user_ || !p || reinterpret_cast<uintptr_t>(p) % 16 != 0) return nullptr;
+    for (HostView &v : views_)
+        if (v.base == p && v.bytes >= bytes) {
+            if (v.dev || v.seen != 1) return v.dev;
+            // Second sight of this array in a row: it is one the caller keeps (SNOPT's own F and G).  Pin it
+            // and map it into the device's address space; a failure is remembered (seen = 2, dev = nullptr).
+            v.seen = 2;
+            void *dev = nullptr;
+            if (hipHostRegister(p, v.bytes, hipHostRegisterMapped) == hipSuccess && hipHostGetDevicePointer(&dev, p, 0) == hipSuccess)
+                v.dev = dev;
+            clear_errors();
+            return v.dev;
+        }
+    // First sight: remember it, use the staging copy this time (arrays that change from call to call are
+    // never registered -- registering costs more than the copy it saves)
+    if (views_.size() >= 16) {
+        for (const HostView &v : views_) if (v.dev) (void)hipHostUnregister(v.base);
+        clear_errors();
+        views_.clear();
+    }
+    views_.push_back(HostView{p, bytes, nullptr, 1});
+    return nullptr;
+}
+
+void problem::stage_and_launch(const double xin[], bool needF, bool needG, double *Fuser, double *Guser)
 {
     ensure_device();
     check(hipSetDevice(eng_->device()), "hipSetDevice");
     std::memcpy(hx_, xin, sizeof(double) * n);
-    // Zero-copy pays while the outputs are small: kernel stores into host memory cross PCIe as
-    // uncached 16-byte writes (measured: ts=200, 202 KB -> 42 vs 52 us per call; ts=2000, 2 MB ->
-    // 338 vs 173 us), so large problems keep the device buffers and DMA copies.
+    void *vF = (needF && Fuser) ? device_view(Fuser, sizeof(double) * neF) : nullptr;
+    void *vG = (needG && Guser) ? device_view(Guser, sizeof(double) * neG) : nullptr;
+    landF_ = vF ? Fuser : hF_;
+    landG_ = vG ? Guser : hG_;
+    // Zero-copy: the kernel's stores cross PCIe as posted writes at ~55 GB/s and the completion word
+    // follows them, so nothing is copied or synchronised (measured per call, profiles/r02_callback.md:
+    // ts=200 22.6 vs 33.6 us staged; ts=2000 52 vs 86 us).  Only problems beyond zero_copy_limit_
+    // (64 MB of x+F+G, ts > ~60000) keep device buffers and DMA copies.
     const bool direct = zero_copy_ && sizeof(double) * ((size_t)n + neF + neG) <= zero_copy_limit_;
+    flagged_ = false;
     if (direct) {
-        // One trajectory is ~200 KB: launch + PCIe latency dominate, not bandwidth.  The kernels read
-        // x from and write F, G to the pinned host buffers directly (they are device-mapped), which
-        // removes three copy commands and their inter-command gaps from every callback.
-        eng_->eval(1, hx_, ldx_, hF_, ldf_, hG_, ldg_, dW_, needF, needG, stream_);
+        // One trajectory is ~200 KB: launch + PCIe latency dominate, not bandwidth.  The kernel reads
+        // x from the pinned copy and writes F, G straight into the caller's (registered) arrays or the
+        // pinned staging buffers, then reports through the completion word: no copy commands, no
+        // stream synchronisation.
+        flagged_ = use_flag_;
+        eng_->eval(1, hx_, ldx_, vF ? vF : hF_, ldf_, vG ? vG : hG_, ldg_, dW_, needF, needG, stream_, nullptr,
+                   flagged_ ? done_ : nullptr, flagged_ ? ++seq_ : 0);
     } else {
         check(hipMemcpyAsync(dX_, hx_, sizeof(double) * n, hipMemcpyHostToDevice, stream_), "H2D x");
         eng_->eval(1, dX_, ldx_, dF_, ldf_, dG_, ldg_, dW_, needF, needG, stream_);
-        if (needF) check(hipMemcpyAsync(hF_, dF_, sizeof(double) * neF, hipMemcpyDeviceToHost, stream_), "D2H F");
-        if (needG) {
+        if (needF) check(hipMemcpyAsync(landF_, dF_, sizeof(double) * neF, hipMemcpyDeviceToHost, stream_), "D2H F");
+        if (needG && vG) {
+            // the DMA engine writes the caller's (registered) array itself: one copy command, nothing to do afterwards
+            check(hipMemcpyAsync(Guser, dG_, sizeof(double) * neG, hipMemcpyDeviceToHost, stream_), "D2H G");
+        } else if (needG) {
             // G comes back in a few pieces, each followed by an event, so that collect() can copy
             // piece i into the caller's array while piece i+1 is still crossing PCIe
             for (int c = 0; c < nchunks_; ++c) {
@@ -430,8 +548,31 @@ void problem::stage_and_launch(const double xin[], bool needF, bool needG)
             }
         }
     }
-    chunked_ = !direct && needG;
+    chunked_ = !direct && needG && !vG;
     staged_ = true; haveF_ = needF; haveG_ = needG;
+}
+
+void problem::wait_done()
+{
+    if (!flagged_) {
+        check(hipStreamSynchronize(stream_), "stream sync");
+        return;
+    }
+    // spin on the completion word; every few thousand polls make sure the stream is still healthy
+    const volatile unsigned long long *flag = done_;
+    for (unsigned long spins = 1;; ++spins) {
+        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq_) break;
+        if ((spins & 0x3fff) == 0) {
+            const hipError_t q = hipStreamQuery(stream_);
+            if (q == hipSuccess) {
+                if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq_) break;
+                throw hip_failure("the evaluation finished without reporting completion");
+            }
+            if (q != hipErrorNotReady) check(q, "stream query");
+        }
+        __builtin_ia32_pause();
+    }
+    flagged_ = false;
 }
 
 void problem::collect(bool wantF, double F[], bool wantG, double G[])
@@ -440,14 +581,14 @@ void problem::collect(bool wantF, double F[], bool wantG, double G[])
         for (int c = 0; c < nchunks_; ++c) {
             const size_t lo = (size_t)neG * c / nchunks_, hi = (size_t)neG * (c + 1) / nchunks_;
             check(hipEventSynchronize(chunk_ev_[c]), "hipEventSynchronize");
-            if (c == 0 && wantF) std::memcpy(F, hF_, sizeof(double) * neF);     // F's copy precedes G's on the stream
+            if (c == 0 && wantF && F != landF_) std::memcpy(F, landF_, sizeof(double) * neF);     // F's copy precedes G's on the stream
             std::memcpy(G + lo, hG_ + lo, sizeof(double) * (hi - lo));
         }
         return;
     }
-    check(hipStreamSynchronize(stream_), "stream sync");
-    if (wantF) std::memcpy(F, hF_, sizeof(double) * neF);
-    if (wantG) std::memcpy(G, hG_, sizeof(double) * neG);
+    wait_done();
+    if (wantF && F != landF_) std::memcpy(F, landF_, sizeof(double) * neF);
+    if (wantG && G != landG_) std::memcpy(G, landG_, sizeof(double) * neG);
 }
 
 void problem::dump(const char *name, const double *v, int len)
@@ -459,17 +600,50 @@ void problem::dump(const char *name, const double *v, int len)
     }
 }
 
+void problem::dump_wind(const double *xin)
+{
+    // ref: the dump at the end of problem::modelWind, src/problem.cpp:740-756 -- one line per node, the twelve
+    // ENU member vectors u v w du_dx du_dy du_dz dv_dx dv_dy dv_dz dw_dx dw_dy dw_dz, "%.6f" each
+    FILE *fp = std::fopen("Woutput.txt", "w");
+    if (!fp) return;
+    const int N = eng_->sizes().N;
+    const tolfg_traj &tr = eng_->trajectory(0);
+    for (int i = 0; i <= N; ++i) {
+        double w[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        const double *s = xin + 11 * i + 1;
+        switch (eng_->windmodel()) {
+        case TOLFG_WIND_SHEAR: {                       // src/problem.cpp:519-524
+            const double zs = -s[2];
+            w[1] = -tr.Vref * zs / tr.href;
+            w[8] = -tr.Vref / tr.href;
+            break;
+        }
+        case TOLFG_WIND_TABLE:
+            for (int f = 0; f < 12 && !wind_host_.empty(); ++f) w[f] = wind_host_[(size_t)f * (N + 1) + i];
+            break;
+        case TOLFG_WIND_GRID:                          // src/problem.cpp:628-692: v, dv_dx (east), dv_dy (north), dv_dz (up)
+            eng_->grid_wind_host(s[0], s[1], s[2], &w[1], &w[6], &w[7], &w[8]);
+            break;
+        default:
+            break;
+        }
+        for (int f = 0; f < 12; ++f) std::fprintf(fp, f < 11 ? "%.6f " : "%.6f\n", w[f]);
+    }
+    std::fclose(fp);
+}
+
 void problem::evaluate(const double xin[], bool needF, double F[], bool needG, double G[])
 {
-    if (debug) dump("Xoutput.txt", xin, n);
+    if (debug) { dump("Xoutput.txt", xin, n); dump_wind(xin); }
     if (!needF && !needG) return;
     static const bool trace = std::getenv("TOLFG_TRACE") != nullptr;     // one line per call on stderr
     if (trace) {
         using clk = std::chrono::steady_clock;
         const auto t0 = clk::now();
-        stage_and_launch(xin, needF, needG);
+        stage_and_launch(xin, needF, needG, F, G);
         const auto t1 = clk::now();
-        check(hipStreamSynchronize(stream_), "stream sync");
+        if (!chunked_) wait_done();
+        else check(hipStreamSynchronize(stream_), "stream sync");
         const auto t2 = clk::now();
         collect(needF, F, needG, G);
         const auto t3 = clk::now();
@@ -479,7 +653,7 @@ void problem::evaluate(const double xin[], bool needF, double F[], bool needG, d
         if (debug && needG) dump("Goutput.txt", G, neG);
         return;
     }
-    stage_and_launch(xin, needF, needG);
+    stage_and_launch(xin, needF, needG, F, G);
     collect(needF, F, needG, G);
     if (debug && needF) dump("Foutput.txt", F, neF);
     if (debug && needG) dump("Goutput.txt", G, neG);

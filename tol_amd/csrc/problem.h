@@ -20,11 +20,13 @@ struct hip_failure : std::runtime_error {
     using std::runtime_error::runtime_error;
 };
 
-int mission_from_name(const std::string &name);   // throws std::invalid_argument (ref: src/tol.cpp:19-23)
+// throws std::invalid_argument (ref: src/tol.cpp:19-23); "mixed" only where a batch may mix missions
+int mission_from_name(const std::string &name, bool allow_mixed = false);
 std::string default_root();
 
 // ---------------------------------------------------------------------------------------------
-// Device-resident evaluation of B independent trajectories that share mission and ts.
+// Device-resident evaluation of B independent trajectories that share ts; mission "S10", "G7" or
+// "mixed" (every trajectory names its own mission; rows are sized for the larger one).
 class batch {
 public:
     batch(const std::string &mission, const std::string &root, const std::vector<std::string> &aircraft_names,
@@ -33,27 +35,39 @@ public:
     batch(const batch &) = delete;
     batch &operator=(const batch &) = delete;
 
+    // row sizes to allocate for: the mission's own, or (mixed) the larger of the two per quantity
     const Sizes &sizes() const { return sz_; }
+    // sizes and pattern of one mission of this batch (MISSION_S10 | MISSION_G7)
+    const Sizes &sizes_of(int mission) const;
+    const Sizes &sizes_of_traj(int t) const { return sizes_of(mission_of_traj(t)); }
+    int mission() const { return mission_; }          // MISSION_S10 | MISSION_G7 | MISSION_MIXED
+    int mission_of_traj(int t) const;
+    double algorithmic_bytes(int B) const;             // elem_size * sum over trajectories of (n + neF + neG)
     int dtype() const { return dtype_; }
     int device() const { return device_; }
     int windmodel() const { return windmodel_; }
     void set_windmodel(int wm) { windmodel_ = wm; }
     size_t elem_size() const { return dtype_ == TOLFG_F64 ? 8 : 4; }
     const aircraft &airframe(int i) const { return acs_.at(i); }
-    const gain &gains() const { return gn_; }
-    const limit &limits() const { return lm_; }
-    const snopt &snopt_params() const { return sn_; }
+    const gain &gains(int mission = -1) const { return gn_.at(slot(mission)); }
+    const limit &limits(int mission = -1) const { return lm_.at(slot(mission)); }
+    const snopt &snopt_params(int mission = -1) const { return sn_.at(slot(mission)); }
 
     void set_wind_grid(const tolfg_wind_grid &g);      // uploads; switches to TOLFG_WIND_GRID
     void set_trajectories(int B, const tolfg_traj *trajs);
     int trajectories() const { return ntraj_; }
     const tolfg_traj &trajectory(int t) const { return host_traj_.at(t); }
     double chi_d(int t) const;
+    // wind model 3 at one NED point, on the host (debug dump only): v and dv/d(east, north, up)
+    bool grid_wind_host(double pn, double pe, double pd, double *v, double *dve, double *dvn, double *dvu) const;
 
     // asynchronous on `stream`
     // dObj (optional, needs needF): the objectives F[t][0] are also written there, contiguous
+    // done (optional, host-mapped word): written with done_seq once every store of this evaluation is
+    // visible to the host -- the SNOPT callback spins on it instead of synchronising the stream
     void eval(int B, const void *dX, long ldx, void *dF, long ldf, void *dG, long ldg, const void *dWind,
-              int needF, int needG, hipStream_t stream, void *dObj = nullptr);
+              int needF, int needG, hipStream_t stream, void *dObj = nullptr,
+              unsigned long long *done = nullptr, unsigned long long done_seq = 0);
     void objectives(int B, const void *dF, long ldf, void *dObj, hipStream_t stream);
     void x0_device(int B, void *dX, long ldx, hipStream_t stream);
     void bounds_device(int B, void *dXlow, void *dXupp, long ldx, void *dFlow, void *dFupp, long ldf, hipStream_t stream);
@@ -63,18 +77,22 @@ public:
 
 private:
     Sizes sz_;
+    Sizes szm_[2];                      // per mission id; both filled for a mixed batch
+    int mission_;
+    int slot(int mission) const { return mission_ == MISSION_MIXED ? (mission < 0 ? 0 : mission) : 0; }
     std::vector<aircraft> acs_;
-    gain gn_;
-    limit lm_;
-    snopt sn_;
+    std::vector<gain> gn_;              // one entry, or [S10, G7] for a mixed batch
+    std::vector<limit> lm_;
+    std::vector<snopt> sn_;
     int windmodel_, dtype_, device_;
     void upload();
-    int waves_per_cu_ = 7;
+    int waves_per_cu_ = 0;              // TOLFG_WAVES_PER_CU (measurements)
     bool waves_forced_ = false;
     bool timing_ = false;
     std::vector<hipEvent_t> ev_;
     size_t ev_used_ = 0;
     void *d_grid_ = nullptr;
+    std::vector<double> grid_host_;
     double *d_partial_ = nullptr;
     long partial_cap_ = 0;
     unsigned *d_counter_ = nullptr;
@@ -82,7 +100,7 @@ private:
     int tile_nodes_forced_ = 0;         // TOLFG_TILE_NODES (measurements)
     bool fused_ = true;                 // TOLFG_FUSED=0 selects fg_kernel + finalize_kernel (measurements)
     int nt_forced_ = -1;                // TOLFG_NT_STORES=0/1 overrides the size-based choice (measurements)
-    bool xcd_ = true;                   // TOLFG_XCD=0: workgroup id -> tile id (measurements)
+    int xcd_forced_ = -1;               // TOLFG_XCD=0/1 overrides the tile order (measurements)
     int ntraj_ = 0, cap_ = 0;
     bool uploaded_ = false;
     TrajDev *d_traj_ = nullptr;
@@ -140,9 +158,24 @@ protected:
 
 private:
     void ensure_device();
-    void stage_and_launch(const double x[], bool needF, bool needG);
+    // Fuser / Guser: the caller's arrays when known at launch time (DEFINEGusrfg_), else nullptr
+    void stage_and_launch(const double x[], bool needF, bool needG, double *Fuser = nullptr, double *Guser = nullptr);
     void collect(bool wantF, double F[], bool wantG, double G[]);
+    void wait_done();
+    // device address of a caller-owned host array, registered on first sight (SNOPT hands the same F and
+    // G arrays to every call: src/snoptProblem.cpp:468-477), or nullptr when it cannot be used directly
+    void *device_view(void *p, size_t bytes);
+    struct HostView { void *base; size_t bytes; void *dev; int seen; };   // seen: 1 = once, 2 = registration tried
+    std::vector<HostView> views_;
+    bool register_user_ = true;                     // TOLFG_NO_REGISTER=1 keeps the pinned staging copies
+    bool use_flag_ = true;                          // TOLFG_NO_FLAG=1 synchronises the stream instead
+    unsigned long long *done_ = nullptr;            // pinned, device-mapped completion word
+    unsigned long long seq_ = 0;
+    bool flagged_ = false;                          // the evaluation in flight reports through done_
+    double *landF_ = nullptr, *landG_ = nullptr;    // where its F and G arrive on the host
     void dump(const char *name, const double *v, int len);
+    void dump_wind(const double *x);
+    std::vector<double> wind_host_;                 // host copy of the table wind, for the dump
 
     hipStream_t stream_ = nullptr;
     static constexpr int kChunks = 6;               // pieces of G's device-to-host copy (staged path)
@@ -153,7 +186,7 @@ private:
     double *dX_ = nullptr, *dF_ = nullptr, *dG_ = nullptr, *dW_ = nullptr;
     long ldx_, ldf_, ldg_;
     bool device_ready_ = false, staged_ = false, haveF_ = false, haveG_ = false;
-    size_t zero_copy_limit_ = 512u << 10;   // bytes of x+F+G up to which the kernels address host memory directly
+    size_t zero_copy_limit_ = 64u << 20;    // bytes of x+F+G up to which the kernels address host memory directly
     bool zero_copy_ = true;           // TOLFG_CALLBACK_STAGING=1 selects explicit H2D/D2H copies instead
 };
 

@@ -166,6 +166,7 @@ class Problem:
 @dataclass
 class Trajectory:
     aircraft: int = 0
+    mission: str = "S10"        # read by "mixed" batches only
     Vref: float = 2.4
     href: float = 10.0
     north_goal: float = 0.0
@@ -177,7 +178,9 @@ class Trajectory:
 
 
 class Batch:
-    """Device-resident evaluation of B trajectories that share mission and ts (one GPU)."""
+    """Device-resident evaluation of B trajectories that share ts (one GPU).  mission: "S10", "G7" or
+    "mixed" -- then every Trajectory names its own mission, n/neF/neG are the row sizes to allocate for
+    (the larger mission's) and sizes_of()/pattern(mission) give one mission's layout."""
 
     def __init__(self, mission, aircraft=("tempest",), ts=0, windmodel=capi.WIND_SHEAR, dtype="f64",
                  device=0, root_path=None, pattern="reference"):
@@ -216,16 +219,30 @@ class Batch:
     def N(self):
         return (self.n - 1) // 11 - 1
 
-    def pattern(self):
-        iG = np.zeros(self.neG, dtype=np.int32)
-        jG = np.zeros(self.neG, dtype=np.int32)
-        check(lib().tolfg_batch_pattern(self._h, _i(iG), _i(jG)))
+    def sizes_of(self, mission):
+        """(n, neF, neG) of one mission of this batch."""
+        n, neF, neG = C.c_int(), C.c_int(), C.c_int()
+        check(lib().tolfg_batch_mission_sizes(self._h, capi.MISSIONS[mission], C.byref(n), C.byref(neF), C.byref(neG)))
+        return n.value, neF.value, neG.value
+
+    def pattern(self, mission=None):
+        if mission is None:
+            iG = np.zeros(self.neG, dtype=np.int32)
+            jG = np.zeros(self.neG, dtype=np.int32)
+            check(lib().tolfg_batch_pattern(self._h, _i(iG), _i(jG)))
+            return iG, jG
+        neG = self.sizes_of(mission)[2]
+        iG = np.zeros(neG, dtype=np.int32)
+        jG = np.zeros(neG, dtype=np.int32)
+        check(lib().tolfg_batch_mission_pattern(self._h, capi.MISSIONS[mission], _i(iG), _i(jG)))
         return iG, jG
 
     def set_trajectories(self, trajs):
         arr = (Traj * len(trajs))()
+        self.missions = [tr.mission if self.mission == "mixed" else self.mission for tr in trajs]
         for t, tr in enumerate(trajs):
             arr[t].aircraft, arr[t].Vref, arr[t].href = tr.aircraft, tr.Vref, tr.href
+            arr[t].mission = capi.MISSIONS[tr.mission] if self.mission == "mixed" else 0
             arr[t].north_goal, arr[t].east_goal, arr[t].radius_goal = tr.north_goal, tr.east_goal, tr.radius_goal
             arr[t].xi, arr[t].yi, arr[t].zi = tr.xi, tr.yi, tr.zi
         check(lib().tolfg_batch_set_trajectories(self._h, len(trajs), arr))
@@ -242,8 +259,9 @@ class Batch:
         return x
 
     def bounds(self, t, zi=0.0):
+        neF = self.sizes_of(self.missions[t])[1]
         xl, xu = np.zeros(self.n), np.zeros(self.n)
-        Fl, Fu = np.zeros(self.neF), np.zeros(self.neF)
+        Fl, Fu = np.zeros(neF), np.zeros(neF)
         check(lib().tolfg_batch_bounds(self._h, int(t), float(zi), _d(xl), _d(xu), _d(Fl), _d(Fu)))
         return xl, xu, Fl, Fu
 
@@ -265,11 +283,41 @@ class Batch:
         G = torch.zeros((B, up(self.neG)), dtype=dt, device=dev)
         return X, F, G
 
+    def _check(self, t, name, rows, cols):
+        """The C ABI takes raw pointers and strides: a tensor of the wrong dtype, device or layout would
+        make the kernels read or write out of bounds, so it is refused here (TOLFG_ERR_ARG)."""
+        import torch
+        why = None
+        if not isinstance(t, torch.Tensor):
+            why = "is not a tensor"
+        elif t.dtype != self.torch_dtype():
+            why = f"has dtype {t.dtype}, the batch computes in {self.torch_dtype()}"
+        elif t.device.type != "cuda" or t.device.index != self.device:
+            why = f"lives on {t.device}, the batch on cuda:{self.device}"
+        elif cols is None:
+            if t.dim() != 1 or t.shape[0] < rows or t.stride(0) != 1:
+                why = f"must be a contiguous vector of at least {rows} elements"
+        elif t.dim() != 2 or t.shape[0] < rows or t.shape[1] < cols or t.stride(1) != 1 or (rows > 1 and t.stride(0) < cols):
+            why = f"must be [>= {rows}][>= {cols}] with unit inner stride, got shape {tuple(t.shape)} strides {tuple(t.stride())}"
+        if why:
+            raise capi.TolfgError(capi.ERR_ARG, f"{name} {why}")
+
     def eval(self, X, F, G, wind=None, needF=True, needG=True, stream=None, B=None, obj=None):
         """Enqueue one evaluation on `stream` (default: torch's current stream).  `obj` (optional,
         B elements) also receives the objectives F[:, 0], contiguous."""
         import torch
         B = X.shape[0] if B is None else B
+        self._check(X, "X", B, self.n)
+        if needF:
+            self._check(F, "F", B, self.neF)
+        if needG:
+            self._check(G, "G", B, self.neG)
+        if wind is not None:
+            if wind.dim() != 3 or not wind.is_contiguous() or tuple(wind.shape[1:]) != (12, self.N + 1):
+                raise capi.TolfgError(capi.ERR_ARG, f"wind must be contiguous [B][12][{self.N + 1}], got {tuple(wind.shape)}")
+            self._check(wind.view(wind.shape[0], -1), "wind", B, 12 * (self.N + 1))
+        if obj is not None:
+            self._check(obj, "obj", B, None)
         if stream is None:
             stream = torch.cuda.current_stream(X.device).cuda_stream
         check(lib().tolfg_batch_eval(self._h, int(B), X.data_ptr(), X.stride(0), F.data_ptr(), F.stride(0),
@@ -281,6 +329,7 @@ class Batch:
         """Initial guess of trajectories [0,B) written into the rows of the device tensor X."""
         import torch
         B = X.shape[0] if B is None else B
+        self._check(X, "X", B, self.n)
         if stream is None:
             stream = torch.cuda.current_stream(X.device).cuda_stream
         check(lib().tolfg_batch_x0_device(self._h, int(B), X.data_ptr(), X.stride(0), C.c_void_p(stream)))
@@ -288,7 +337,10 @@ class Batch:
     def bounds_device(self, xlow, xupp, Flow, Fupp, stream=None, B=None):
         import torch
         B = xlow.shape[0] if B is None else B
-        assert xlow.stride(0) == xupp.stride(0) and Flow.stride(0) == Fupp.stride(0)
+        for t, name, cols in ((xlow, "xlow", self.n), (xupp, "xupp", self.n), (Flow, "Flow", self.neF), (Fupp, "Fupp", self.neF)):
+            self._check(t, name, B, cols)
+        if xlow.stride(0) != xupp.stride(0) or Flow.stride(0) != Fupp.stride(0):
+            raise capi.TolfgError(capi.ERR_ARG, "xlow/xupp and Flow/Fupp must share their row strides")
         if stream is None:
             stream = torch.cuda.current_stream(xlow.device).cuda_stream
         check(lib().tolfg_batch_bounds_device(self._h, int(B), xlow.data_ptr(), xupp.data_ptr(), xlow.stride(0),
@@ -297,8 +349,10 @@ class Batch:
     def objectives(self, F, out=None, stream=None, B=None):
         import torch
         B = F.shape[0] if B is None else B
+        self._check(F, "F", B, 1)
         if out is None:
             out = torch.empty(B, dtype=F.dtype, device=F.device)
+        self._check(out, "out", B, None)
         if stream is None:
             stream = torch.cuda.current_stream(F.device).cuda_stream
         check(lib().tolfg_batch_objectives(self._h, int(B), F.data_ptr(), F.stride(0), out.data_ptr(),

@@ -37,8 +37,8 @@ Shape make_shape(int B, int N, int mission, int dtype)
     Shape s{};
     s.B = B; s.N = N; s.mission = mission; s.dtype = dtype;
     s.n = 11L * (N + 1) + 1;
-    s.neF = 8L * N + 1 + (mission == tolfg::MISSION_S10 ? 11 : 12);
-    s.neG = mission == tolfg::MISSION_S10 ? 107L * N + 37 : 105L * N + 48;
+    s.neF = 8L * N + 1 + (mission == tolfg::MISSION_S10 ? 11 : 12);      // mixed: rows sized for the larger mission
+    s.neG = mission == tolfg::MISSION_G7 ? 105L * N + 48 : 107L * N + 37;
     s.c0 = mission == tolfg::MISSION_S10 ? 3 * N + 4 : N + 6;
     const long v = dtype == 0 ? 2 : 4;
     auto up = [&](long m) { return (m + v - 1) / v * v; };
@@ -100,11 +100,14 @@ void fill(Buffers &bf, const Shape &sh, int xbuf)
         tr[b] = tolfg::TrajDev{};
         tr[b].shear = 0.1 + 0.3 * ((b * 37) % 100) / 100.0;
         tr[b].xg = 0.0; tr[b].yg = 400.0; tr[b].rg = 100.0; tr[b].cchi = 0.0; tr[b].schi = 1.0; tr[b].ac = 0;
+        tr[b].mission = sh.mission == tolfg::MISSION_MIXED ? (b & 1) : sh.mission;
     }
     CK(hipMalloc(&bf.dF, bf.es() * sh.B * sh.ldf));
     CK(hipMalloc(&bf.dG, bf.es() * sh.B * sh.ldg));
     CK(hipMalloc(&bf.dF2, bf.es() * sh.B * sh.ldf));
     CK(hipMalloc(&bf.dG2, bf.es() * sh.B * sh.ldg));
+    CK(hipMemset(bf.dF2, 0xff, bf.es() * sh.B * sh.ldf));      // rows of a mixed batch leave their tails untouched
+    CK(hipMemset(bf.dG2, 0xff, bf.es() * sh.B * sh.ldg));
     CK(hipMalloc(&bf.dT, sizeof(tolfg::TrajDev) * sh.B));
     CK(hipMalloc(&bf.dC, sizeof(unsigned) * sh.B));
     CK(hipMemset(bf.dC, 0, sizeof(unsigned) * sh.B));
@@ -116,7 +119,7 @@ tolfg::FgArgs make_args(Buffers &bf, int max_nt, int cap, int fused, int xi, voi
     const Shape &sh = bf.sh;
     tolfg::FgArgs a{};
     a.X = bf.dX[xi % bf.dX.size()]; a.ldx = sh.ldx; a.F = F; a.ldf = sh.ldf; a.G = G; a.ldg = sh.ldg;
-    a.wind = nullptr; a.traj = bf.dT; a.B = sh.B; a.N = sh.N; a.c0 = sh.c0;
+    a.wind = nullptr; a.traj = bf.dT; a.B = sh.B; a.N = sh.N; a.c0[0] = 3 * sh.N + 4; a.c0[1] = sh.N + 6;
     tolfg::plan_tiles(sh.N, sh.dtype, max_nt, &a.tiles, &a.nt);
     const long W = (long)sh.B * a.tiles;
     if (W > bf.capW) {
@@ -134,10 +137,20 @@ tolfg::FgArgs make_args(Buffers &bf, int max_nt, int cap, int fused, int xi, voi
         bf.poll_ready = -1;
     }
     a.needF = 1; a.needG = 1; a.pattern = tolfg::PATTERN_REFERENCE; a.waves_per_cu = cap;
-    if (sh.mission == tolfg::MISSION_S10) { a.kT = 0.3; a.kp = 8; a.kv = 0; a.kdt = 1; }
-    else { a.kT = 100; a.kp = 0.7; a.kv = 0.4; a.kdt = 0; }
+    a.kT[0] = 0.3; a.kp[0] = 8; a.kv[0] = 0; a.kdt[0] = 1;
+    a.kT[1] = 100; a.kp[1] = 0.7; a.kv[1] = 0.4; a.kdt[1] = 0;
     a.ac[0] = tolfg::AcCoef{1.0 / 6.1228, 1.2682 * 0.6316 / (2 * 6.1228), 0.03, 1.0 / (16.4457 * M_PI * 0.9693), 6.1228, 0.6316, 16.4457, 0.9693};
     return a;
+}
+
+// widest slab store the slab regions of this shape are aligned for (c0 of every mission present)
+int slab_vec(const Shape &sh)
+{
+    int sv = sh.dtype == 0 ? 2 : 4;
+    for (int m = 0; m < 2; m++)
+        if (sh.mission == tolfg::MISSION_MIXED || sh.mission == m)
+            while (sv > 1 && (m == 0 ? 3 * sh.N + 4 : sh.N + 6) % sv) sv >>= 1;
+    return sv;
 }
 
 long compare(const Buffers &bf)
@@ -189,25 +202,25 @@ int main(int argc, char **argv)
             bf.nt = 1; bf.xcd = 0;
             tolfg::FgArgs r = make_args(bf, 64, 0, 0, 0, bf.dF2, bf.dG2);     // reference result of this shape
             bf.nt = nt_keep; bf.xcd = xcd_keep;
-            CK(tolfg::launch_fg(r, sh.mission, tolfg::WIND_SHEAR, sh.dtype, sh.dtype == 0 ? 2 : 4, st));
+            CK(tolfg::launch_fg(r, sh.mission, tolfg::WIND_SHEAR, sh.dtype, sh.dtype == 0 ? 2 : 4, slab_vec(sh), st));
             CK(hipStreamSynchronize(st));
         }
         const int vec = sh.dtype == 0 ? 2 : 4;
         tolfg::FgArgs a = make_args(bf, v[2], v[3], v[4], 0, bf.dF, bf.dG);
         CK(hipMemsetAsync(bf.dF, 0xff, bf.es() * sh.B * sh.ldf, st));
         CK(hipMemsetAsync(bf.dG, 0xff, bf.es() * sh.B * sh.ldg, st));
-        CK(tolfg::launch_fg(a, sh.mission, tolfg::WIND_SHEAR, sh.dtype, vec, st));
+        CK(tolfg::launch_fg(a, sh.mission, tolfg::WIND_SHEAR, sh.dtype, vec, slab_vec(sh), st));
         CK(hipStreamSynchronize(st));
         const long bad = compare(bf);
         for (int w = 0; w < 5; w++) {
             tolfg::FgArgs aw = make_args(bf, v[2], v[3], v[4], w, bf.dF, bf.dG);
-            CK(tolfg::launch_fg(aw, sh.mission, tolfg::WIND_SHEAR, sh.dtype, vec, st));
+            CK(tolfg::launch_fg(aw, sh.mission, tolfg::WIND_SHEAR, sh.dtype, vec, slab_vec(sh), st));
         }
         CK(hipStreamSynchronize(st));
         CK(hipEventRecord(e0, st));
         for (int r = 0; r < reps; r++) {
             tolfg::FgArgs ar = make_args(bf, v[2], v[3], v[4], r, bf.dF, bf.dG);
-            CK(tolfg::launch_fg(ar, sh.mission, tolfg::WIND_SHEAR, sh.dtype, vec, st));
+            CK(tolfg::launch_fg(ar, sh.mission, tolfg::WIND_SHEAR, sh.dtype, vec, slab_vec(sh), st));
         }
         CK(hipEventRecord(e1, st));
         CK(hipEventSynchronize(e1));
@@ -216,13 +229,13 @@ int main(int argc, char **argv)
         // repeat of the check after the timed launches: the counters must have been left at zero
         CK(hipMemsetAsync(bf.dF, 0xff, bf.es() * sh.B * sh.ldf, st));
         CK(hipMemsetAsync(bf.dG, 0xff, bf.es() * sh.B * sh.ldg, st));
-        CK(tolfg::launch_fg(a, sh.mission, tolfg::WIND_SHEAR, sh.dtype, vec, st));
+        CK(tolfg::launch_fg(a, sh.mission, tolfg::WIND_SHEAR, sh.dtype, vec, slab_vec(sh), st));
         CK(hipStreamSynchronize(st));
         const long bad2 = compare(bf);
         const double bytes = (double)bf.es() * sh.B * ((double)sh.n + sh.neF + sh.neG);
         const double us = 1e3 * ms / reps;
         printf("| %d | %d | %s | %s | %d -> %d x %d | %d | %d%s%s | %.2f | %.0f | %.1f | %s |\n", sh.B, sh.N,
-               sh.mission == 0 ? "S10" : "G7", sh.dtype == 0 ? "f64" : "f32", v[2], a.tiles, a.nt, v[3], v[4],
+               sh.mission == 0 ? "S10" : (sh.mission == 1 ? "G7" : "mixed"), sh.dtype == 0 ? "f64" : "f32", v[2], a.tiles, a.nt, v[3], v[4],
                bf.nt ? " nt" : " plain", bf.xcd ? " xcd" : "", us,
                bytes / (1e3 * us), 100.0 * bytes / (1e3 * us) / 8000.0, (bad || bad2) ? "MISMATCH" : "ok");
         fflush(stdout);

@@ -63,8 +63,9 @@ int main(int argc, char **argv)
 
     tolfg::FgArgs a{};
     a.X = dX; a.ldx = ldx; a.F = dF; a.ldf = ldf; a.G = dG; a.ldg = ldg; a.wind = nullptr; a.traj = dT;
-    a.B = B; a.N = N; a.tiles = tiles; a.nt = nt; a.partial = dP; a.obj = nullptr; a.c0 = 3 * N + 4; a.needF = 1; a.needG = 1;
-    a.kT = 0; a.kp = 8; a.kv = 0; a.kdt = 1;
+    a.B = B; a.N = N; a.tiles = tiles; a.nt = nt; a.partial = dP; a.obj = nullptr; a.c0[0] = 3 * N + 4; a.c0[1] = N + 6; a.needF = 1; a.needG = 1;
+    a.kT[0] = 0; a.kp[0] = 8; a.kv[0] = 0; a.kdt[0] = 1;
+    a.nt_stores = 1;
     a.ac[0] = tolfg::AcCoef{1.0 / 6.1228, 1.2682 * 0.6316 / (2 * 6.1228), 0.03, 1.0 / (16.4457 * M_PI * 0.9693)};
     a.stamps = dS; a.variant = variant;
     a.waves_per_cu = argc > 5 ? atoi(argv[5]) : 0;
@@ -73,10 +74,10 @@ int main(int argc, char **argv)
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     if (variant & 8192) a.needF = 0;
-    for (int i = 0; i < 5; i++) CK(tolfg::launch_fg(a, tolfg::MISSION_S10, tolfg::WIND_SHEAR, 0, 2, nullptr));
+    for (int i = 0; i < 5; i++) CK(tolfg::launch_fg(a, tolfg::MISSION_S10, tolfg::WIND_SHEAR, 0, 2, 2, nullptr));
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0));
-    for (int i = 0; i < reps; i++) CK(tolfg::launch_fg(a, tolfg::MISSION_S10, tolfg::WIND_SHEAR, 0, 2, nullptr));
+    for (int i = 0; i < reps; i++) CK(tolfg::launch_fg(a, tolfg::MISSION_S10, tolfg::WIND_SHEAR, 0, 2, 2, nullptr));
     CK(hipEventRecord(e1));
     CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));

@@ -4,7 +4,7 @@
 # Counters are collected in their own passes (kernel-trace only, no other trace domains).
 set -e
 TAG=${1:-r01}
-ARGS=${2:-"--steps 50 --warmup 5 --no-cpu-baseline --no-callback"}
+ARGS=${2:-"--steps 50 --warmup 5 --no-cpu-baseline --no-configs"}
 OUT=$PWD/gpurun_out/prof_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
 export TMPDIR=/tmp
