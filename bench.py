@@ -154,31 +154,35 @@ def cpu_baseline(args, seconds):
 
 
 def callback_mode(tol_amd, mission, aircraft, ts, calls, cfg=None):
-    """Single-trajectory SNOPT-callback rate: host x -> host F, G through DEFINEGusrfg_, entered the
-    way snOptA does (all arguments by reference, prepared once: the loop times the C ABI, not the
-    construction of ctypes objects; F and G are the same arrays every call, as SNOPT's are)."""
+    """Single-trajectory SNOPT-callback rate: host x -> host F, G through DEFINEGusrfg_.  Main figure: the call
+    entered from native code through an snFunA pointer, as snOptA enters it (tolfg_time_callback); beside it the
+    same call entered from Python through ctypes (adds the foreign-call overhead of the test harness).  F and G
+    are the same arrays every call, as SNOPT's are."""
     import ctypes as C
     p = tol_amd.Problem(mission, aircraft, ts=ts)
+    x = np.ascontiguousarray(p.x0())
+    us_native, F, G = p.time_callback(x, calls)
+    assert np.isfinite(F).all() and np.isfinite(G).all() and F[0] != 0.0
     p.make_current()
     L = tol_amd.lib()
     dp = C.POINTER(C.c_double)
-    x = np.ascontiguousarray(p.x0())
-    F, G = np.zeros(p.neF), np.zeros(p.neG)
     st, n, neF, neG = C.c_int(1), C.c_int(p.n), C.c_int(p.neF), C.c_int(p.neG)
     one, zero = C.c_int(1), C.c_int(0)
     argv = (C.byref(st), C.byref(n), x.ctypes.data_as(dp), C.byref(one), C.byref(neF), F.ctypes.data_as(dp),
             C.byref(one), C.byref(neG), G.ctypes.data_as(dp), None, C.byref(zero), None, C.byref(zero), None, C.byref(zero))
     fn = L.DEFINEGusrfg_
-    for _ in range(50):
+    for _ in range(20):
         fn(*argv)
     t0 = time.perf_counter()
     for _ in range(calls):
         fn(*argv)
     dt = time.perf_counter() - t0
-    assert st.value == 1 and np.isfinite(F).all()
+    assert st.value == 1
     p.close()
     rec = {"workload": f"{mission}/{aircraft}/ts={ts} single trajectory, DEFINEGusrfg_ host->host (PCIe inclusive)",
-           "mode": "callback", "us_per_call": 1e6 * dt / calls, "node_evals_per_s": calls * ts / dt, "calls": calls}
+           "mode": "callback", "us_per_call": us_native, "node_evals_per_s": 1e6 * ts / us_native, "calls": calls,
+           "entered_from": "native code through an snFunA pointer (tolfg_time_callback)",
+           "us_per_call_via_python_ctypes": 1e6 * dt / calls}
     if cfg is not None:
         rec["config"] = cfg
     return rec

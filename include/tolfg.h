@@ -151,6 +151,12 @@ void DEFINEGusrfg_(int *Status, int *n, double x[],
                    int iu[], int *leniu,
                    double ru[], int *lenru);
 
+/* Measurement aid: enter DEFINEGusrfg_ `calls` times from native code through an snFunA function pointer,
+ * the way snOptA does (x, F, G: caller arrays of the problem's sizes, the same ones every call), after
+ * `warm` untimed calls; *us_per_call receives the mean wall time of one call.  Returns the last *Status
+ * the callback left (1 = untouched) or a negative TOLFG_ERR_*. */
+int tolfg_time_callback(tolfg_problem *p, const double *x, double *F, double *G, int warm, int calls, double *us_per_call);
+
 /* The three public methods DEFINEGusrfg_ dispatches to in the reference
  * (ref: problem::modelWind / computeF / computeG, src/problem.cpp:475,765,782), for callers that
  * drive them separately.  modelWind stages x on the device; computeF / computeG evaluate on demand

@@ -34,15 +34,17 @@ def random_wind_table(N, seed, scale=0.3):
 # ---- fp32 I/O variant: bounds per row class, about 4x the worst case measured on the mixed 8192-trajectory
 # batch (profiles/r01_fp32_sweep.md, re-measured profiles/r02_fp32_sweep.md): objective 2.1e-7,
 # x/y/z defects 9.4e-6, Va/gam/chi defects 1.6e-6, phi/CL defects 4.8e-7, boundary rows 4.1e-6 (scaled).
-FP32_TOL = {"objective": 1e-6, "r1-r3": 4e-5, "r4-r6": 8e-6, "r7-r8": 2e-6, "boundary": 2e-5}
+# The objective ROW of G holds per-node entries kp (r-R)(x-xg)/r, whose (r-R) cancels in float32 when a node sits
+# near the goal ring (seen: 1.8e-6 on a 0.25 entry), hence a class of its own.
+FP32_TOL = {"objective": 1e-6, "objective-gradient": 1e-5, "r1-r3": 4e-5, "r4-r6": 8e-6, "r7-r8": 2e-6, "boundary": 2e-5}
 
 
-def row_class_masks(rows, N):
+def row_class_masks(rows, N, jacobian=False):
     """class name -> boolean mask over an array of F-row indices (np.arange(neF) for F, iGfun for G)."""
     rows = np.asarray(rows)
     r = (rows - 1) % 8 + 1
     dyn = (rows >= 1) & (rows < 8 * N + 1)
-    return {"objective": rows == 0, "r1-r3": dyn & (r <= 3), "r4-r6": dyn & (r >= 4) & (r <= 6),
+    return {"objective-gradient" if jacobian else "objective": rows == 0, "r1-r3": dyn & (r <= 3), "r4-r6": dyn & (r >= 4) & (r <= 6),
             "r7-r8": dyn & (r >= 7), "boundary": rows >= 8 * N + 1}
 
 
@@ -51,7 +53,7 @@ def assert_close_f32(F, G, Fo, Go, iG, N, mask=None, what="", scale=1.0):
     `scale` loosens every class bound by a stated factor for inputs harsher than the sweep's."""
     worst = {}
     for arr, ref, rows, msk, tag in ((F, Fo, np.arange(len(Fo)), None, "F"), (G, Go, iG, mask, "G")):
-        for cname, m in row_class_masks(rows, N).items():
+        for cname, m in row_class_masks(rows, N, jacobian=tag == "G").items():
             if not m.any():
                 continue
             sub = None if msk is None else msk[m]

@@ -204,13 +204,13 @@ def test_mixed_batch_equals_single_mission_batches(tolfg, oracle, dtype):
         one.x0_device(sX)
         sxl, sxu, sFl, sFu = torch.empty_like(sX), torch.empty_like(sX), torch.empty_like(sF), torch.empty_like(sF)
         one.bounds_device(sxl, sxu, sFl, sFu)
-        assert_close(x0_mixed[off::2, :one.n].double().cpu().numpy(), sX[:, :one.n].double().cpu().numpy(), tol=tight, what=f"x0 {m}")
+        flat = lambda t: t.double().cpu().numpy().ravel()      # noqa: E731
+        assert_close(flat(x0_mixed[off::2, :one.n]), flat(sX[:, :one.n]), tol=tight, what=f"x0 {m}")
         sX[:, :one.n] = dX[off::2, :one.n]            # the same decision vectors as the mixed batch saw
         one.eval(sX, sF, sG)
         torch.cuda.synchronize()
-        assert_close(dF[off::2, :one.neF].double().cpu().numpy(), sF[:, :one.neF].double().cpu().numpy(), tol=tight, what=f"F {m}")
-        und = np.zeros(one.neG, dtype=bool)
-        assert_close(dG[off::2, :one.neG].double().cpu().numpy(), sG[:, :one.neG].double().cpu().numpy(), tol=tight, what=f"G {m}")
+        assert_close(flat(dF[off::2, :one.neF]), flat(sF[:, :one.neF]), tol=tight, what=f"F {m}")
+        assert_close(flat(dG[off::2, :one.neG]), flat(sG[:, :one.neG]), tol=tight, what=f"G {m}")
         # bounds are constants: bitwise
         assert torch.equal(xl[off::2, :one.n], sxl[:, :one.n]) and torch.equal(xu[off::2, :one.n], sxu[:, :one.n])
         assert torch.equal(Fl[off::2, :one.neF], sFl[:, :one.neF]) and torch.equal(Fu[off::2, :one.neF], sFu[:, :one.neF])

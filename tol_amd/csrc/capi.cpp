@@ -1,5 +1,6 @@
 // capi.cpp -- the extern "C" surface declared in include/tolfg.h.  No exception leaves this file:
 // the SNOPT callback is entered from a Fortran frame (ref: f_snkera, src/snoptProblem.cpp:468).
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <mutex>
@@ -219,6 +220,25 @@ void DEFINEGusrfg_(int *Status, int *n, double x[], int *needF, int *neF, double
         std::fprintf(stderr, "tolfg: %s\n", g_err.c_str());
         if (Status) *Status = -2;   // snOptA: a value <= -2 asks SNOPT to terminate
     }
+}
+
+int tolfg_time_callback(tolfg_problem *h, const double *x, double *F, double *G, int warm, int calls, double *us_per_call)
+{
+    if (!h || !x || !F || !G || calls < 1 || !us_per_call) return fail(TOLFG_ERR_ARG, "tolfg_time_callback: bad argument");
+    typedef void (*snFunA)(int *, int *, double *, int *, int *, double *, int *, int *, double *, char *, int *, int *, int *,
+                           double *, int *);     // ref: include/snopt/snopt.h:60-66
+    volatile snFunA usrfun = DEFINEGusrfg_;
+    tolfg_problem *keep = g_current;
+    tolfg_set_current(h);
+    int Status = 1, n = h->p->n, neF = h->p->neF, neG = h->p->neG, one = 1, zero = 0;
+    std::vector<double> xs(x, x + n);
+    for (int i = 0; i < warm; ++i) usrfun(&Status, &n, xs.data(), &one, &neF, F, &one, &neG, G, nullptr, &zero, nullptr, &zero, nullptr, &zero);
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int i = 0; i < calls; ++i) usrfun(&Status, &n, xs.data(), &one, &neF, F, &one, &neG, G, nullptr, &zero, nullptr, &zero, nullptr, &zero);
+    const auto t1 = std::chrono::steady_clock::now();
+    *us_per_call = std::chrono::duration<double, std::micro>(t1 - t0).count() / calls;
+    tolfg_set_current(keep);
+    return Status;
 }
 
 int tolfg_modelWind(tolfg_problem *h, const double *x)

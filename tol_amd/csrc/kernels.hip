@@ -9,20 +9,25 @@
 //     problem::dynamicsGradients src/problem.cpp:1035-1208, wind models 0/1/3 src/problem.cpp:480-695,
 //     problemS10::cost/costGradient src/problemS10.cpp:227-386, problemG7::... src/problemG7.cpp:225-384).
 //   * finalize_body: one wavefront per trajectory, lanes = output entries, adds the tiles' objective
-//     terms in tile order (deterministic, no atomics), handles the last node's terms and writes the
-//     boundary rows and their gradients (ref: src/problemS10.cpp:273-305,395-415;
+//     terms in one fixed order (deterministic, no floating-point atomics), handles the last node's terms
+//     and writes the boundary rows and their gradients (ref: src/problemS10.cpp:273-305,395-415;
 //     src/problemG7.cpp:258-296,393-513).
-//   * batched path: fg_kernel (one 64-lane workgroup per tile) + finalize_kernel.  One tile per
-//     workgroup on purpose: workgroups that walk several tiles, or several waves that start together,
-//     stay in phase, and measured 5-10 % slower.  The launch requests more LDS than a tile uses to cap
-//     the resident waves per CU at 7-8: the kernel is bound by the HBM write path, which serves
-//     fewer concurrent store streams better.
+//   * batched path: fg_kernel, one 64-lane workgroup per tile, ONE launch per evaluation: the tile wave
+//     that arrives last at its trajectory's counter runs finalize_body (Publish / sum_partials: payload
+//     through write-through stores, polled, nobody waits).  One tile per workgroup on purpose:
+//     workgroups that walk several tiles, or several waves that start together, stay in phase, and
+//     measured 5-10 % slower.  Tiles are dealt to the 8 XCDs in contiguous eighths.  When the outputs
+//     exceed the Infinity Cache the launch requests more LDS than a tile uses to cap the resident
+//     waves per CU (the kernel is bound by the HBM write path, which serves fewer concurrent store
+//     streams better) and the slab stream is non-temporal; when they fit, plain stores and no cap.
 //   * callback path (a few short trajectories): fg_single_kernel, whole trajectory per workgroup,
-//     one launch.
+//     one launch, optional completion word for the spinning host.
+//   * a mixed batch (MISSION_MIXED) reads each trajectory's mission from its record; a tile is one
+//     trajectory, so the branch is wave-uniform.
 //   * the SNOPT-facing layouts are node-major (x[11k+1+m], G slab c0+104k), so a lane-per-node
 //     access is 88 B / 832 B strided.  The x window is therefore loaded with contiguous 16-byte
 //     loads and transposed through LDS, and the slabs (83 % of all bytes) are written with
-//     contiguous non-temporal 16-byte stores, 1 KiB per wave instruction.  Of the 104 slab elements
+//     contiguous 16-byte stores, 1 KiB per wave instruction.  Of the 104 slab elements
 //     only 32 are computed per node; the 58 structural zeros and the +-1 constants are injected from
 //     a compile-time table while streaming out, so the LDS exchange is 35 elements per node
 //     (17.9 KB per wave in fp64).  F (64 B per node) and the objective-gradient entries (24 B per
@@ -38,6 +43,7 @@
 #include "slab_table.h"
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 namespace tolfg {
 
@@ -87,7 +93,39 @@ constexpr int gcd_c(int a, int b) { return b == 0 ? a : gcd_c(b, a % b); }
 template <typename T, int VEC> struct Vec { typedef T type __attribute__((ext_vector_type(VEC))); };
 template <typename T> struct Vec<T, 1> { typedef T type; };
 
-__device__ __forceinline__ void sincos_t(double a, double &s, double &c) { sincos(a, &s, &c); }
+// sin and cos of a double, both at once.  The angles on this path (flight-path angle, course, bank) are a few
+// radians at most, so the common case is a two-constant Cody-Waite reduction by pi/2 (exact products through
+// FMA) and the classic degree-13 / degree-14 minimax kernels on [-pi/4, pi/4]; |a| >= 2^17 (or NaN) takes the
+// library routine with its full-range reduction.  Worst observed difference from libm: 1 ulp; about a third
+// of the library routine's instructions, which shortens every tile wave's dependent chain (three per node).
+__device__ __forceinline__ void sincos_t(double a, double &s, double &c)
+{
+    if (!(fabs(a) < 131072.0)) {
+        sincos(a, &s, &c);
+        return;
+    }
+    const double k = rint(a * 0.63661977236758134308);             // 2/pi
+    double r = fma(-k, 1.57079632679489655800e+00, a);              // pi/2, high part
+    r = fma(-k, 6.12323399573676603587e-17, r);                     // pi/2, low part
+    const double z = r * r;
+    double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    ps = fma(z, ps, 2.75573137070700676789e-06);
+    ps = fma(z, ps, -1.98412698298579493134e-04);
+    ps = fma(z, ps, 8.33333333332248946124e-03);
+    ps = fma(z, ps, -1.66666666666666324348e-01);
+    const double sn = fma(z * r, ps, r);
+    double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    pc = fma(z, pc, -2.75573143513906633035e-07);
+    pc = fma(z, pc, 2.48015872894767294178e-05);
+    pc = fma(z, pc, -1.38888888888741095749e-03);
+    pc = fma(z, pc, 4.16666666666666019037e-02);
+    const double hz = 0.5 * z, w = 1.0 - hz;
+    const double cs = w + (((1.0 - w) - hz) + z * z * pc);
+    const int q = (int)k & 3;
+    const double s0 = (q & 1) ? cs : sn, c0 = (q & 1) ? sn : cs;
+    s = (q & 2) ? -s0 : s0;
+    c = ((q + 1) & 2) ? -c0 : c0;
+}
 __device__ __forceinline__ void sincos_t(float a, float &s, float &c) { sincosf(a, &s, &c); }
 __device__ __forceinline__ double sqrt_t(double a) { return sqrt(a); }
 __device__ __forceinline__ float sqrt_t(float a) { return sqrtf(a); }
@@ -822,27 +860,33 @@ hipError_t launch_vec(const FgArgs &a, int vec, int svec, dim3 grid, hipStream_t
             return t1 ? hipEventRecord(t1, s) : hipSuccess;
         }
     }
-    if (t0 && (e = hipEventRecord(t0, s)) != hipSuccess) return e;
+    // Timing events ride on the dispatches themselves (hipExtLaunchKernelGGL: the kernel's own start / end
+    // timestamps, no extra commands on the stream): t0 = start of fg_kernel, t1 = end of the evaluation's
+    // last kernel (fg_kernel when fused, else finalize_kernel).
     const unsigned lds = (unsigned)fg_lds_request(sizeof(T) == 8 ? 0 : 1, a.waves_per_cu);
+    hipEvent_t fg_end = a.fused ? t1 : nullptr;
+    auto go = [&](auto kernel, dim3 g, unsigned ldsz, hipEvent_t st, hipEvent_t en) {
+        if (st || en) hipExtLaunchKernelGGL(kernel, g, dim3(TILE), ldsz, s, st, en, 0, a);
+        else hipLaunchKernelGGL(kernel, g, dim3(TILE), ldsz, s, a);
+    };
     if (vec == VMAX && svec == VMAX) {
-        if (a.nt_stores) hipLaunchKernelGGL((fg_kernel<T, MISSION, WIND, VMAX, VMAX, PAT, true>), grid, dim3(TILE), lds, s, a);
-        else             hipLaunchKernelGGL((fg_kernel<T, MISSION, WIND, VMAX, VMAX, PAT, false>), grid, dim3(TILE), lds, s, a);
+        if (a.nt_stores) go(fg_kernel<T, MISSION, WIND, VMAX, VMAX, PAT, true>, grid, lds, t0, fg_end);
+        else             go(fg_kernel<T, MISSION, WIND, VMAX, VMAX, PAT, false>, grid, lds, t0, fg_end);
     } else if (VMAX == 4 && vec == VMAX && svec == 2) {
         // fp32 rows whose slab regions sit on 8-byte boundaries only (c0 % 4 == 2): 16-byte loads, 8-byte slab stores
         constexpr int SV2 = VMAX == 4 ? 2 : VMAX;
-        if (a.nt_stores) hipLaunchKernelGGL((fg_kernel<T, MISSION, WIND, VMAX, SV2, PAT, true>), grid, dim3(TILE), lds, s, a);
-        else             hipLaunchKernelGGL((fg_kernel<T, MISSION, WIND, VMAX, SV2, PAT, false>), grid, dim3(TILE), lds, s, a);
+        if (a.nt_stores) go(fg_kernel<T, MISSION, WIND, VMAX, SV2, PAT, true>, grid, lds, t0, fg_end);
+        else             go(fg_kernel<T, MISSION, WIND, VMAX, SV2, PAT, false>, grid, lds, t0, fg_end);
     } else {
-        hipLaunchKernelGGL((fg_kernel<T, MISSION, WIND, 1, 1, PAT, false>), grid, dim3(TILE), lds, s, a);
+        go(fg_kernel<T, MISSION, WIND, 1, 1, PAT, false>, grid, lds, t0, fg_end);
     }
     e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (!a.fused) {
-        hipLaunchKernelGGL((finalize_kernel<T, MISSION, PAT>), dim3(a.B), dim3(TILE), 0, s, a);
+        go(finalize_kernel<T, MISSION, PAT>, dim3(a.B), 0u, nullptr, t1);
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
-    // the events bracket the whole evaluation: fg_kernel, and finalize_kernel when it is a launch of its own
-    return t1 ? hipEventRecord(t1, s) : hipSuccess;
+    return hipSuccess;
 }
 
 template <typename T, int MISSION, int PAT>

@@ -8,4 +8,4 @@ for _ in range(reps):
   for (m, a, ts, c) in (("S10", "tempest", 100, 500), ("S10", "tempest", 200, 500), ("S10", "tempest", 500, 300),
                       ("S10", "skywalker", 2000, 200), ("G7", "tempest", 100, 500)):
         r = bench.callback_mode(tol_amd, m, a, ts, c)
-        print(m, a, ts, "%.1f us/call  %.3g node-evals/s" % (r["us_per_call"], r["node_evals_per_s"]))
+        print(m, a, ts, "%.1f us/call native (%.1f through ctypes)  %.3g node-evals/s" % (r["us_per_call"], r["us_per_call_via_python_ctypes"], r["node_evals_per_s"]))

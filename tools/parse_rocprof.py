@@ -57,7 +57,7 @@ def main():
     md = []
     md.append(f"# rocprofv3 summary `{tag}` -- bench.py, S10/tempest/ts={ts}/{dtype}, batch {batch} per GPU, 1 MI355X\n")
     md.append("Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 50 --warmup 5 "
-              "--no-cpu-baseline --no-callback` (tools/profile_gpu.sh); counters from two further passes of the same "
+              "--no-cpu-baseline --no-configs` (tools/profile_gpu.sh); counters from two further passes of the same "
               "command with `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE`.\n")
     md.append("## Kernel time (`--stats`)\n")
     md.append("| kernel | calls | avg us | min us | max us | % |\n|---|---|---|---|---|---|")
@@ -66,8 +66,12 @@ def main():
                   f"{float(r['MaxNs'])/1e3:.2f} | {r['Percentage']} |")
     md.append("\n## fg_kernel launch\n")
     md.append(f"- grid {t0['Grid_Size_X']} threads = {int(t0['Grid_Size_X'])//64} workgroups of {t0['Workgroup_Size_X']}; "
-              f"VGPR {t0['VGPR_Count']}, AGPR {t0['Accum_VGPR_Count']}, SGPR {t0['SGPR_Count']}, LDS {t0['LDS_Block_Size']} B, "
-              f"scratch {t0['Scratch_Size']} B")
+              f"rocprofv3's trace columns: VGPR_Count {t0['VGPR_Count']}, Accum_VGPR_Count {t0['Accum_VGPR_Count']}, "
+              f"SGPR_Count {t0['SGPR_Count']}, LDS_Block_Size {t0['LDS_Block_Size']} B, Scratch_Size {t0['Scratch_Size']} B "
+              f"-- these are the profiler's own accounting (its VGPR figure is not the code object's, and it shows the "
+              f"STATIC LDS only).  The code object (tools/isa_report.py) says next_free_vgpr 100, no scratch; the kernel's LDS "
+              f"is dynamic: 17 920 B are used per workgroup and the launch requests 160 KiB / cap so that at most `cap` "
+              f"one-wave workgroups share a CU (tol_amd/csrc/plan.cpp)")
     md.append(f"- algorithmic bytes per launch = {elem} B x {batch} x (n {n} + neF {neF} + neG {neG}) = {alg/1e6:.2f} MB "
               f"({alg/(batch*ts):.1f} B per node)")
     md.append(f"- average duration {avg_ns/1e3:.2f} us  ->  **{alg/avg_ns:.1f} GB/s algorithmic = {alg/avg_ns/80:.1f} % of the "
@@ -82,7 +86,8 @@ def main():
     with open(os.path.join(dst, tag + "_summary.md"), "w") as fh:
         fh.write("\n".join(md) + "\n")
     with open(os.path.join(dst, "traffic_latest.json"), "w") as fh:
-        json.dump({"tag": tag, "batch": batch, "ts": ts, "dtype": dtype,
+        json.dump({"tag": tag, "batch": batch, "ts": ts, "dtype": dtype, "mission": "S10", "pattern": "reference",
+                   "source": f"tools/profile_gpu.sh {tag} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
                    "hbm_bytes_per_launch": read_bytes + write_bytes,
                    "read_bytes": read_bytes, "write_bytes": write_bytes,
                    "fetch_size_kib_raw": fetch_kib, "write_size_kib_raw": write_kib,

@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""Print the essentials of a bench.py JSON line (file argument or stdin)."""
+import json
+import sys
+
+txt = open(sys.argv[1]).read() if len(sys.argv) > 1 else sys.stdin.read()
+d = json.loads(txt.strip().splitlines()[-1])
+r = d["roofline"]
+print("value %.4g %s on %d GPU(s), %s scaling, backend %s; ms/step %.4f; evaluation %.4f ms (min %.4f) -> %.0f GB/s = %.3f of peak"
+      % (d["value"], d["unit"], d["n_gpus"], d["scaling"], d.get("backend"), d["ms_per_step"], r["kernel_ms"], r["kernel_min_ms"], r["achieved"], r["frac"]))
+for c in d.get("configs", []):
+    if c["mode"] == "callback":
+        print("  config %d callback: %.1f us/call native (%.1f via ctypes) = %.3g node-evals/s  [%s]"
+              % (c["config"], c["us_per_call"], c["us_per_call_via_python_ctypes"], c["node_evals_per_s"], c["workload"]))
+    else:
+        print("  config %d B=%d %s: step %.1f us, evaluation %.1f us (min %.1f) = %.0f GB/s = %.3f of peak, %.3g node-evals/s  [%s]"
+              % (c["config"], c["batch"], c["dtype"], 1e3 * c["ms_per_step"], c["eval_us"], c["eval_min_us"], c["achieved_GBs"], c["frac_of_hbm_peak"],
+                 c["node_evals_per_s"], c["workload"]))
+if "cpu_baseline" in d:
+    b = d["cpu_baseline"]
+    print("  cpu baseline (%s, %d core): %.4g %s; -O0 %.4g; fused 1 core %.4g; fused %d cores %.4g"
+          % (b["kind"], b["cores"], b["value"], b["unit"], b["value_O0"], b["fused_one_core"]["value"], b["fused_all_cores"]["cores"], b["fused_all_cores"]["value"]))
+if "next_compact_pattern" in d:
+    c = d["next_compact_pattern"]
+    print("  compact pattern: %.4g node-evals/s, evaluation %.4f ms = %.3f of peak" % (c["value"], c["kernel_ms"], c["frac_of_hbm_peak"]))
