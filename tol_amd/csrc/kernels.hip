@@ -100,6 +100,10 @@ template <typename T> struct Vec<T, 1> { typedef T type; };
 // of the library routine's instructions, which shortens every tile wave's dependent chain (three per node).
 __device__ __forceinline__ void sincos_t(double a, double &s, double &c)
 {
+#ifdef TOLFG_LIB_SINCOS      // A/B switch of tools/fgbench.cpp
+    sincos(a, &s, &c);
+    return;
+#endif
     if (!(fabs(a) < 131072.0)) {
         sincos(a, &s, &c);
         return;

@@ -5,7 +5,7 @@
 // waves-per-CU cap and the fused/unfused finalize can be compared inside ONE gpurun call:
 //
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o tools/bin/fgbench tools/fgbench.cpp
-//   tools/bin/fgbench [reps=N] [xbuf=K] B,N,max_nt,cap,fused[,mission[,dtype]] ...
+//   tools/bin/fgbench [reps=N] [xbuf=K] [nt=0|1] [xcd=0|1] [pat=0|1] B,N,max_nt,cap,fused[,mission[,dtype]] ...
 //
 // Every configuration is first checked against the reference configuration of its shape
 // (max_nt 64, unfused): defects and G must agree bitwise, the objective to 1e-13 relative.
@@ -54,7 +54,7 @@ struct Buffers {
     double *dP = nullptr;
     unsigned *dC = nullptr;
     long capW = 0, poll_ready = -1;
-    int nt = 1, xcd = 0;
+    int nt = 1, xcd = 0, pat = 0;
     size_t es() const { return sh.dtype == 0 ? 8 : 4; }
     void release()
     {
@@ -136,7 +136,8 @@ tolfg::FgArgs make_args(Buffers &bf, int max_nt, int cap, int fused, int xi, voi
     } else if (!fused) {
         bf.poll_ready = -1;
     }
-    a.needF = 1; a.needG = 1; a.pattern = tolfg::PATTERN_REFERENCE; a.waves_per_cu = cap;
+    a.needF = 1; a.needG = 1; a.pattern = bf.pat; a.waves_per_cu = cap;
+    if (bf.pat == tolfg::PATTERN_COMPACT) { a.c0[0] = 3 * sh.N + 4; a.c0[1] = sh.N + 6; }
     a.kT[0] = 0.3; a.kp[0] = 8; a.kv[0] = 0; a.kdt[0] = 1;
     a.kT[1] = 100; a.kp[1] = 0.7; a.kv[1] = 0.4; a.kdt[1] = 0;
     a.ac[0] = tolfg::AcCoef{1.0 / 6.1228, 1.2682 * 0.6316 / (2 * 6.1228), 0.03, 1.0 / (16.4457 * M_PI * 0.9693), 6.1228, 0.6316, 16.4457, 0.9693};
@@ -191,6 +192,7 @@ int main(int argc, char **argv)
         if (!strncmp(argv[i], "xbuf=", 5)) { xbuf = atoi(argv[i] + 5); bf.release(); bf.sh = Shape{}; continue; }
         if (!strncmp(argv[i], "nt=", 3)) { bf.nt = atoi(argv[i] + 3); continue; }
         if (!strncmp(argv[i], "xcd=", 4)) { bf.xcd = atoi(argv[i] + 4); continue; }
+        if (!strncmp(argv[i], "pat=", 4)) { bf.pat = atoi(argv[i] + 4); bf.release(); bf.sh = Shape{}; continue; }
         int v[7] = {4096, 200, 64, 0, 0, 0, 0};
         int nv = 0;
         for (char *tok = strtok(argv[i], ","); tok && nv < 7; tok = strtok(nullptr, ",")) v[nv++] = atoi(tok);
@@ -232,7 +234,8 @@ int main(int argc, char **argv)
         CK(tolfg::launch_fg(a, sh.mission, tolfg::WIND_SHEAR, sh.dtype, vec, slab_vec(sh), st));
         CK(hipStreamSynchronize(st));
         const long bad2 = compare(bf);
-        const double bytes = (double)bf.es() * sh.B * ((double)sh.n + sh.neF + sh.neG);
+        const long neG_eff = bf.pat == tolfg::PATTERN_COMPACT ? sh.c0 + 46L * sh.N + (sh.mission == tolfg::MISSION_G7 ? 30 : 22) : sh.neG;
+        const double bytes = (double)bf.es() * sh.B * ((double)sh.n + sh.neF + neG_eff);
         const double us = 1e3 * ms / reps;
         printf("| %d | %d | %s | %s | %d -> %d x %d | %d | %d%s%s | %.2f | %.0f | %.1f | %s |\n", sh.B, sh.N,
                sh.mission == 0 ? "S10" : (sh.mission == 1 ? "G7" : "mixed"), sh.dtype == 0 ? "f64" : "f32", v[2], a.tiles, a.nt, v[3], v[4],
