@@ -97,6 +97,7 @@ struct LaunchPlan {
     int waves_per_cu;      // cap on resident tile waves per CU, 0 = none
     int nt_stores;         // non-temporal slab stream
     int xcd;               // deal the tiles to the XCDs in contiguous eighths
+    int fused;             // the last-arriving tile wave finalizes (one launch) vs finalize_kernel as a second launch
 };
 LaunchPlan plan_launch(double out_bytes, int dtype, int pattern);
 

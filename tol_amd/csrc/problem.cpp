@@ -109,7 +109,7 @@ batch::batch(const std::string &mission, const std::string &root, const std::vec
     args_.N = N;
     plan_tiles(N, dtype, 0, &args_.tiles, &args_.nt);      // eval() re-plans for its batch size
     if (const char *e = std::getenv("TOLFG_TILE_NODES")) tile_nodes_forced_ = std::atoi(e);
-    if (const char *e = std::getenv("TOLFG_FUSED")) fused_ = std::atoi(e) != 0;
+    if (const char *e = std::getenv("TOLFG_FUSED")) fused_forced_ = std::atoi(e) != 0;
     if (const char *e = std::getenv("TOLFG_NT_STORES")) nt_forced_ = std::atoi(e) != 0;
     if (const char *e = std::getenv("TOLFG_XCD")) xcd_forced_ = std::atoi(e) != 0;
     for (int m = 0; m < 2; ++m) {
@@ -285,7 +285,7 @@ void batch::eval(int B, const void *dX, long ldx, void *dF, long ldf, void *dG, 
     }
     a.partial = d_partial_;
     a.counter = d_counter_;
-    a.fused = (fused_ || done) ? 1 : 0;          // a completion word needs the single-launch form
+    a.fused = ((fused_forced_ >= 0 ? fused_forced_ : lp.fused) || done) ? 1 : 0;   // a completion word needs the single-launch form
     a.obj = dObj;
     a.done = done; a.done_seq = done_seq;
     a.waves_per_cu = waves_forced_ ? waves_per_cu_ : lp.waves_per_cu;

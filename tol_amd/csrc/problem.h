@@ -98,7 +98,7 @@ private:
     unsigned *d_counter_ = nullptr;
     int counter_cap_ = 0;
     int tile_nodes_forced_ = 0;         // TOLFG_TILE_NODES (measurements)
-    bool fused_ = true;                 // TOLFG_FUSED=0 selects fg_kernel + finalize_kernel (measurements)
+    int fused_forced_ = -1;             // TOLFG_FUSED=0/1 overrides one launch vs fg_kernel + finalize_kernel (measurements)
     int nt_forced_ = -1;                // TOLFG_NT_STORES=0/1 overrides the size-based choice (measurements)
     int xcd_forced_ = -1;               // TOLFG_XCD=0/1 overrides the tile order (measurements)
     int ntraj_ = 0, cap_ = 0;

@@ -152,6 +152,9 @@ def main():
         ("G7", 6, "tempest", (400.0, 0.0, 70.0, 0.0), (0.0, 0.0, 0.0)),
         ("S10", 9, "skywalker", (250.0, -120.0, 70.0, 80.0), (15.0, -25.0, -40.0)),
         ("G7", 9, "skywalker", (300.0, 200.0, 70.0, 0.0), (-20.0, 30.0, -55.0)),
+        # odd ts: c0 is odd, so the product takes its scalar-store kernels; 20 nodes: more than one 16-node store group
+        ("S10", 13, "tempest", (380.0, 40.0, 70.0, 120.0), (5.0, 8.0, -35.0)),
+        ("G7", 20, "tempest", (350.0, -150.0, 70.0, 0.0), (12.0, -7.0, -45.0)),
     ]
     for ci, (mission, N, airframe, goal, start) in enumerate(spec):
         rng = np.random.default_rng(4200 + ci)
