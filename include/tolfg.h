@@ -228,7 +228,8 @@ int  tolfg_batch_bounds(const tolfg_batch *b, int t, double zi,
  * issue it inside a hipGraph capture -- warm up once, then capture (tests/test_gpu_parity.py does). */
 /* Evaluate F and G of trajectories [0,B) in one launch.  dX, dF, dG, dWind are DEVICE pointers to
  * elements of the batch dtype; row t of X/F/G starts ldx/ldf/ldg elements after row t-1
- * (ld >= n / neF / neG; even ld keeps 16-byte stores).  dWind is NULL unless windmodel is
+ * (ld >= n / neF / neG; dX and dF on 16-byte boundaries with ldx, ldf even -- multiples of 4 for fp32 -- keep the
+ * 16-byte window loads and defect stores; G may sit anywhere, its slabs are always streamed with 16-byte stores).  dWind is NULL unless windmodel is
  * TOLFG_WIND_TABLE, then [B][12][ts+1].  dObj is NULL or a device array of B elements that also
  * receives the objectives F[t][0], contiguous (needs needF).  stream is a hipStream_t (NULL =
  * default stream).  Asynchronous: returns after enqueueing. */

@@ -279,3 +279,38 @@ def test_extreme_shapes(tolfg, oracle, mission, B, N):
         Fo, Go = o.eval(x)
         assert_close(dF[t, :bt.neF].cpu().numpy(), Fo, what=f"extreme F[{t}]")
         assert_close(dG[t, :bt.neG].cpu().numpy(), Go, mask=o.undefined_mask(), what=f"extreme G[{t}]")
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("mission,N", [("S10", 5), ("G7", 6), ("S10", 7), ("G7", 200), ("S10", 201)])
+def test_slab_stream_at_every_alignment(tolfg, oracle, mission, N, dtype):
+    """The Jacobian slabs are streamed with 16-byte stores wherever the slab regions sit relative to a 16-byte
+    boundary: odd c0 (odd ts), c0 % 4 == 2 in fp32 (G7 at ts = 200), and a G whose rows start 1, 2 or 3 elements past
+    a boundary.  Elements before and after every row's G are guard values and must survive."""
+    import torch
+    B = 11
+    rg = 100.0 if mission == "S10" else 0.0
+    bt = tolfg.Batch(mission, ["tempest"], ts=N, dtype=dtype)
+    bt.set_trajectories([tolfg.Trajectory(radius_goal=rg, Vref=1.0 + 0.3 * t) for t in range(B)])
+    ops = [oracle.Problem(mission, "tempest", N=N, radius_goal=rg, Vref=1.0 + 0.3 * t) for t in range(B)]
+    X = np.stack([oracle.perturbed(ops[t], 60 + t) for t in range(B)])
+    dX, dF, _ = bt.alloc(B)
+    dX[:, :bt.n] = torch.from_numpy(X).to(bt.torch_dtype()).cuda()
+    Xin = dX[:, :bt.n].double().cpu().numpy()
+    ref = [ops[t].eval(Xin[t]) for t in range(B)]
+    iG = bt.pattern()[0]
+    vmax = 2 if dtype == "f64" else 4
+    ld = (bt.neG + 2 * vmax + vmax - 1) // vmax * vmax
+    for k in range(vmax):
+        big = torch.full((B, ld), -777.0, dtype=bt.torch_dtype(), device="cuda")
+        dG = big[:, k:k + bt.neG + 1]            # rows start k elements past a 16-byte boundary; one guard column inside the view
+        bt.eval(dX, dF, dG)
+        torch.cuda.synchronize()
+        assert torch.all(big[:, :k] == -777.0) and torch.all(big[:, k + bt.neG:] == -777.0), f"guard elements overwritten (offset {k})"
+        for t in range(B):
+            Ft, Gt = dF[t, :bt.neF].double().cpu().numpy(), big[t, k:k + bt.neG].double().cpu().numpy()
+            if dtype == "f64":
+                assert_close(Ft, ref[t][0], what=f"F[{t}] offset {k}")
+                assert_close(Gt, ref[t][1], mask=ops[t].undefined_mask(), what=f"G[{t}] offset {k}")
+            else:
+                assert_close_f32(Ft, Gt, ref[t][0], ref[t][1], iG, N, mask=ops[t].undefined_mask(), what=f"f32 [{t}] offset {k}")

@@ -259,3 +259,42 @@ def test_gain_weighted_terms_with_non_shipped_gains(tolfg, oracle, tmp_path, mis
             assert_close(Gt, pick(Go), mask=pick(ops[t].undefined_mask()), what=f"gains batch G[{t}]")
         else:
             assert_close_f32(Ft, Gt, Fo, pick(Go), iG, N, mask=pick(ops[t].undefined_mask()), what=f"gains batch f32 [{t}]")
+
+
+@pytest.mark.parametrize("mission", ["S10", "G7"])
+def test_batched_need_flags_and_repeated_launches(tolfg, oracle, mission):
+    """The tile-per-workgroup path (B > 8) honours needF / needG like the callback does, in any order of launches:
+    the objective partial slots of the single-launch form are empty again after every launch (also after one
+    that did not ask for F), and 30 further launches reproduce the first one bit for bit."""
+    import torch
+    N, B = 200, 20
+    rg = 100.0 if mission == "S10" else 0.0
+    bt = tolfg.Batch(mission, ["tempest", "skywalker"], ts=N)
+    bt.set_trajectories([tolfg.Trajectory(aircraft=t % 2, radius_goal=rg, Vref=0.5 + 0.2 * t) for t in range(B)])
+    ops = [oracle.Problem(mission, ("tempest", "skywalker")[t % 2], N=N, radius_goal=rg, Vref=0.5 + 0.2 * t) for t in range(B)]
+    X = np.stack([oracle.perturbed(ops[t], 800 + t) for t in range(B)])
+    dX, dF, dG = bt.alloc(B)
+    dX[:, :bt.n] = torch.from_numpy(X).cuda()
+    ref = [ops[t].eval(X[t]) for t in range(B)]
+
+    def check(F_expected, G_expected):
+        torch.cuda.synchronize()
+        for t in range(B):
+            if F_expected:
+                assert_close(dF[t, :bt.neF].cpu().numpy(), ref[t][0], what=f"F[{t}]")
+            else:
+                assert torch.isnan(dF).all()
+            if G_expected:
+                assert_close(dG[t, :bt.neG].cpu().numpy(), ref[t][1], mask=ops[t].undefined_mask(), what=f"G[{t}]")
+            else:
+                assert torch.isnan(dG).all()
+
+    for needF, needG in ((False, True), (True, False), (False, False), (True, True), (False, True), (True, True)):
+        dF.fill_(float("nan")); dG.fill_(float("nan"))
+        bt.eval(dX, dF, dG, needF=needF, needG=needG)
+        check(needF, needG)
+    F0, G0 = dF.clone(), dG.clone()
+    for _ in range(30):
+        bt.eval(dX, dF, dG)
+    torch.cuda.synchronize()
+    assert torch.equal(dF[:, :bt.neF], F0[:, :bt.neF]) and torch.equal(dG[:, :bt.neG], G0[:, :bt.neG])   # pad columns hold NaN

@@ -102,11 +102,11 @@ struct LaunchPlan {
 LaunchPlan plan_launch(double out_bytes, int dtype, int pattern);
 
 // One evaluation on stream s: F and G of B trajectories.  dtype: 0 = f64, 1 = f32.  vec = elements per
-// 16-byte access the caller has verified alignment of X, F and the row strides for (f64: 2 or 1;
-// f32: 4 or 1); svec <= vec = elements per slab store the slab regions (G + c0) are aligned for
-// (f32 with c0 % 4 == 2, e.g. G7 at ts = 200: vec 4, svec 2).
+// 16-byte access the caller has verified alignment of X, F and their row strides for (f64: 2 or 1;
+// f32: 4 or 1).  The Jacobian slabs are always streamed with 16-byte stores: wherever a slab region sits
+// relative to a 16-byte boundary (odd c0, or c0 % 4 == 2 in fp32), the wave shifts its stream.
 // t0/t1 (may be null) are recorded on s around the whole evaluation.
-hipError_t launch_fg(const FgArgs &a, int mission, int wind, int dtype, int vec, int svec, hipStream_t s,
+hipError_t launch_fg(const FgArgs &a, int mission, int wind, int dtype, int vec, hipStream_t s,
                      hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr);
 
 // dObj[t] = F[t*ldf]

@@ -320,7 +320,11 @@ template <int PAT, int GV> struct SlabGeom {
     static_assert(SLABN % GV == 0, "slab must be a whole number of vectors");
 };
 
-template <typename T, int PAT, int GV> struct SlabOffsets {
+// SHIFT: the slab region starts SHIFT elements past a 16-byte boundary (c0 odd, or c0 % 4 == 2 in fp32).
+// The stream is then cut SHIFT elements earlier: vector q covers elements [q*GV - SHIFT, q*GV - SHIFT + GV),
+// every vector 1 <= q < total is whole and aligned, and the first GV - SHIFT and the last SHIFT elements
+// leave as scalars.  A vector may then straddle two nodes, so each element carries its own node.
+template <typename T, int PAT, int GV, int SHIFT> struct SlabOffsets {
     typedef SlabGeom<PAT, GV> Gm;
     unsigned pk[Gm::P][(GV + 1) / 2];
     __device__ __forceinline__ static int code(int e)
@@ -328,17 +332,27 @@ template <typename T, int PAT, int GV> struct SlabOffsets {
         if constexpr (PAT == PATTERN_COMPACT) return kSlabCompact.c[e];
         else return kSlabFull.c[e];
     }
+    // LDS offset of stream element r of a period, relative to the row of the node BEFORE the period's
+    // first one when SHIFT > 0 (r may be negative then), else relative to the period's first row
+    __device__ __forceinline__ static unsigned elem(int r)
+    {
+        if constexpr (SHIFT == 0) {
+            const int nd = r / Gm::SLABN;
+            return (unsigned)(nd * RS + code(r - nd * Gm::SLABN));
+        } else {
+            const int nd = (r + Gm::SLABN) / Gm::SLABN;          // = floor(r / SLABN) + 1 for r >= -SLABN
+            return (unsigned)(nd * RS + code(r + Gm::SLABN - nd * Gm::SLABN));
+        }
+    }
     __device__ __forceinline__ void init(int lane)
     {
 #pragma unroll
         for (int t = 0; t < Gm::P; t++) {
-            const int pp = TILE * t + lane;
-            const int nd = pp / Gm::PN;
-            const int e = (pp - nd * Gm::PN) * GV;
+            const int r0 = (TILE * t + lane) * GV - SHIFT;
 #pragma unroll
             for (int h = 0; h < (GV + 1) / 2; h++) {
-                unsigned lo = nd * RS + code(e + 2 * h);
-                unsigned hi = (2 * h + 1 < GV) ? nd * RS + code(e + 2 * h + 1) : 0u;
+                const unsigned lo = elem(r0 + 2 * h);
+                const unsigned hi = (2 * h + 1 < GV) ? elem(r0 + 2 * h + 1) : 0u;
                 pk[t][h] = lo | (hi << 16);
             }
         }
@@ -350,29 +364,57 @@ template <typename T, int PAT, int GV> struct SlabOffsets {
     }
 };
 
-template <typename T, int PAT, int GV, bool NT>
-__device__ __forceinline__ void store_slabs(const T *lds, T *gslab, int cnt, int lane, const SlabOffsets<T, PAT, GV> &so)
+template <typename T, int PAT, int GV, bool NT, int SHIFT>
+__device__ __forceinline__ void store_slabs(const T *lds, T *gslab, int cnt, int lane)
 {
     typedef typename Vec<T, GV>::type vec;
     typedef SlabGeom<PAT, GV> Gm;
+    SlabOffsets<T, PAT, GV, SHIFT> so;
+    so.init(lane);
     const int total = Gm::PN * cnt;
 #pragma unroll 1
     for (int j = 0; j < Gm::NPER; j++) {
         if (j * Gm::NPP >= cnt) break;   // wave-uniform
-        const T *grp = lds + j * Gm::NPP * RS;
+        const T *grp = lds + (j * Gm::NPP - (SHIFT ? 1 : 0)) * RS;
 #pragma unroll
         for (int t = 0; t < Gm::P; t++) {
             const int p = TILE * (Gm::P * j + t) + lane;
-            if (p < total) {
+            if (p < total && (SHIFT == 0 || p >= 1)) {
                 if constexpr (GV == 1) {
                     stream_store<NT>(gslab + p, grp[so.off(t, 0)]);
                 } else {
                     vec val;
 #pragma unroll
                     for (int v = 0; v < GV; v++) val[v] = grp[so.off(t, v)];
-                    stream_store<NT>(reinterpret_cast<vec *>(gslab + (long)p * GV), val);
+                    stream_store<NT>(reinterpret_cast<vec *>(gslab + (long)p * GV - SHIFT), val);
                 }
             }
+        }
+    }
+    if constexpr (SHIFT > 0) {
+        // head: elements [0, GV - SHIFT) of the first node; tail: the last SHIFT elements of the last node
+        if (lane < GV - SHIFT) gslab[lane] = lds[SlabOffsets<T, PAT, GV, 0>::code(lane)];
+        else if (lane < GV) {
+            const int e = Gm::SLABN - GV + lane;           // SLABN - SHIFT + (lane - (GV - SHIFT))
+            gslab[(long)Gm::SLABN * (cnt - 1) + e] = lds[(cnt - 1) * RS + SlabOffsets<T, PAT, GV, 0>::code(e)];
+        }
+    }
+}
+
+// The slab region's position relative to a 16-byte boundary is wave-uniform (it depends on the row's base
+// address and c0 only: SLABN * k0 is a multiple of the vector width because k0 is a multiple of 4).
+template <typename T, int PAT, int GV, bool NT>
+__device__ __forceinline__ void stream_slabs(const T *lds, T *gslab, int cnt, int lane)
+{
+    if constexpr (GV == 1) {
+        store_slabs<T, PAT, 1, NT, 0>(lds, gslab, cnt, lane);
+    } else {
+        const int shift = __builtin_amdgcn_readfirstlane((int)((reinterpret_cast<unsigned long long>(gslab) / sizeof(T)) % GV));
+        if (shift == 0) store_slabs<T, PAT, GV, NT, 0>(lds, gslab, cnt, lane);
+        else if (shift == 1) store_slabs<T, PAT, GV, NT, 1>(lds, gslab, cnt, lane);
+        else if constexpr (GV == 4) {
+            if (shift == 2) store_slabs<T, PAT, GV, NT, 2>(lds, gslab, cnt, lane);
+            else store_slabs<T, PAT, GV, NT, 3>(lds, gslab, cnt, lane);
         }
     }
 }
@@ -425,13 +467,13 @@ struct Publish {
 
 // One tile: everything a wavefront does for `cnt` consecutive nodes of trajectory b.  lds is the
 // wave's own TILE*RS-element region; sumT / sumP return the tile's objective terms (wave-uniform).
-template <typename T, int MISSION, int WIND, int VEC, int SV, int PAT, bool NT>
+template <typename T, int MISSION, int WIND, int VEC, int PAT, bool NT>
 __device__ __forceinline__ void tile_body(const FgArgs &a, T *lds, int item, int lane, T &sumT_out, T &sumP_out, Publish &pub)
 {
     typedef typename Vec<T, VEC>::type vec;
-    // slab stores: SV elements per lane (16 bytes where alignment allows), and where the slab length
-    // allows (46 floats are 23 pairs, not quads)
-    constexpr int GV = (PAT == PATTERN_COMPACT && SV == 4) ? 2 : SV;
+    // slab stores: 16 bytes per lane whatever the region's alignment (stream_slabs shifts the stream), where
+    // the slab length allows (46 floats are 23 pairs, not quads)
+    constexpr int GV = (PAT == PATTERN_COMPACT && sizeof(T) == 4) ? 2 : (int)(16 / sizeof(T));
     constexpr int SLABN = SlabGeom<PAT, GV>::SLABN;
     constexpr int NW = ((NI * TILE + 9 + VEC - 1) / VEC + TILE - 1) / TILE;   // window vectors per lane
     const int N = a.N;
@@ -549,9 +591,7 @@ __device__ __forceinline__ void tile_body(const FgArgs &a, T *lds, int item, int
         __syncthreads();
         TOLFG_STAMP(a, 3);
         __builtin_amdgcn_sched_barrier(0);
-        SlabOffsets<T, PAT, GV> so;
-        so.init(lane);
-        if (!(TOLFG_VARIANT(a) & 2048)) store_slabs<T, PAT, GV, NT>(lds, Grow + a.c0[ms] + (long)SLABN * k0, cnt, lane, so);
+        if (!(TOLFG_VARIANT(a) & 2048)) stream_slabs<T, PAT, GV, NT>(lds, Grow + a.c0[ms] + (long)SLABN * k0, cnt, lane);
         TOLFG_STAMP(a, 4);
     }
     TOLFG_STAMP(a, 5);
@@ -747,7 +787,7 @@ __device__ __forceinline__ void sum_partials(const double *part, int tiles, int 
 // profiles/r02_write_shapes.md); otherwise consecutive workgroups walk the memory in order.
 // Fused form (a.fused): the wave that arrives last at its trajectory's counter also finalizes it, so
 // an evaluation is one launch; otherwise finalize_kernel follows.
-template <typename T, int MISSION, int WIND, int VEC, int SV, int PAT, bool NT>
+template <typename T, int MISSION, int WIND, int VEC, int PAT, bool NT>
 __global__ __launch_bounds__(TILE, TOLFG_MIN_WAVES_PER_SIMD) void fg_kernel(const FgArgs a)
 {
     // dynamic LDS: TILE*RS elements are used; the launch may request more to cap the waves per CU
@@ -766,7 +806,7 @@ __global__ __launch_bounds__(TILE, TOLFG_MIN_WAVES_PER_SIMD) void fg_kernel(cons
         pub.slot = a.partial + 2 * (long)item;
         pub.counter = a.counter + b;
     }
-    tile_body<T, MISSION, WIND, VEC, SV, PAT, NT>(a, reinterpret_cast<T *>(lds_raw), item, lane, sumT, sumP, pub);
+    tile_body<T, MISSION, WIND, VEC, PAT, NT>(a, reinterpret_cast<T *>(lds_raw), item, lane, sumT, sumP, pub);
     if (a.fused) {
         const unsigned old = __builtin_amdgcn_readfirstlane(pub.old);
         if (old == (unsigned)(a.tiles - 1)) {          // wave-uniform: every tile of b has arrived
@@ -813,7 +853,7 @@ __global__ __launch_bounds__(8 * TILE) void fg_single_kernel(const FgArgs a)
     }
     T sumT, sumP;
     Publish pub{nullptr, nullptr, 0u};
-    tile_body<T, MISSION, WIND, VEC, VEC, PAT, false>(a, lds + (long)w * TILE * RS, b * a.tiles + w, lane, sumT, sumP, pub);
+    tile_body<T, MISSION, WIND, VEC, PAT, false>(a, lds + (long)w * TILE * RS, b * a.tiles + w, lane, sumT, sumP, pub);
     if (lane == 0) { red[2 * w] = (double)sumT; red[2 * w + 1] = (double)sumP; }
     if (w == 0 && lane < 23) edge[lane] = pre;
     __syncthreads();
@@ -839,7 +879,7 @@ __global__ void objectives_kernel(const T *F, long ldf, T *obj, int B)
 }
 
 template <typename T, int MISSION, int WIND, int PAT>
-hipError_t launch_vec(const FgArgs &a, int vec, int svec, dim3 grid, hipStream_t s, hipEvent_t t0, hipEvent_t t1)
+hipError_t launch_vec(const FgArgs &a, int vec, dim3 grid, hipStream_t s, hipEvent_t t0, hipEvent_t t1)
 {
     constexpr int VMAX = 16 / sizeof(T);
     hipError_t e;
@@ -851,7 +891,7 @@ hipError_t launch_vec(const FgArgs &a, int vec, int svec, dim3 grid, hipStream_t
             const unsigned ldsz = (unsigned)(a.tiles * TILE * RS * sizeof(T) + 16 * a.tiles + 24 * sizeof(T));
             const dim3 g1(a.B), b1(TILE * a.tiles);
             if (t0 && (e = hipEventRecord(t0, s)) != hipSuccess) return e;
-            if (vec == VMAX && svec == VMAX) {
+            if (vec == VMAX) {
                 auto kf = fg_single_kernel<T, MISSION, WIND, VMAX, PAT>;
                 if (ldsz > 64 * 1024 && (e = hipFuncSetAttribute(reinterpret_cast<const void *>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, ldsz)) != hipSuccess) return e;
                 hipLaunchKernelGGL(kf, g1, b1, ldsz, s, a);
@@ -873,16 +913,12 @@ hipError_t launch_vec(const FgArgs &a, int vec, int svec, dim3 grid, hipStream_t
         if (st || en) hipExtLaunchKernelGGL(kernel, g, dim3(TILE), ldsz, s, st, en, 0, a);
         else hipLaunchKernelGGL(kernel, g, dim3(TILE), ldsz, s, a);
     };
-    if (vec == VMAX && svec == VMAX) {
-        if (a.nt_stores) go(fg_kernel<T, MISSION, WIND, VMAX, VMAX, PAT, true>, grid, lds, t0, fg_end);
-        else             go(fg_kernel<T, MISSION, WIND, VMAX, VMAX, PAT, false>, grid, lds, t0, fg_end);
-    } else if (VMAX == 4 && vec == VMAX && svec == 2) {
-        // fp32 rows whose slab regions sit on 8-byte boundaries only (c0 % 4 == 2): 16-byte loads, 8-byte slab stores
-        constexpr int SV2 = VMAX == 4 ? 2 : VMAX;
-        if (a.nt_stores) go(fg_kernel<T, MISSION, WIND, VMAX, SV2, PAT, true>, grid, lds, t0, fg_end);
-        else             go(fg_kernel<T, MISSION, WIND, VMAX, SV2, PAT, false>, grid, lds, t0, fg_end);
-    } else {
-        go(fg_kernel<T, MISSION, WIND, 1, 1, PAT, false>, grid, lds, t0, fg_end);
+    if (vec == VMAX) {
+        if (a.nt_stores) go(fg_kernel<T, MISSION, WIND, VMAX, PAT, true>, grid, lds, t0, fg_end);
+        else             go(fg_kernel<T, MISSION, WIND, VMAX, PAT, false>, grid, lds, t0, fg_end);
+    } else {              // rows of X or F off 16-byte boundaries: scalar window loads and defect stores
+        if (a.nt_stores) go(fg_kernel<T, MISSION, WIND, 1, PAT, true>, grid, lds, t0, fg_end);
+        else             go(fg_kernel<T, MISSION, WIND, 1, PAT, false>, grid, lds, t0, fg_end);
     }
     e = hipGetLastError();
     if (e != hipSuccess) return e;
@@ -894,25 +930,25 @@ hipError_t launch_vec(const FgArgs &a, int vec, int svec, dim3 grid, hipStream_t
 }
 
 template <typename T, int MISSION, int PAT>
-hipError_t launch_wind(const FgArgs &a, int wind, int vec, int svec, dim3 grid, hipStream_t s, hipEvent_t t0, hipEvent_t t1)
+hipError_t launch_wind(const FgArgs &a, int wind, int vec, dim3 grid, hipStream_t s, hipEvent_t t0, hipEvent_t t1)
 {
     switch (wind) {
-    case WIND_NONE:  return launch_vec<T, MISSION, WIND_NONE, PAT>(a, vec, svec, grid, s, t0, t1);
-    case WIND_SHEAR: return launch_vec<T, MISSION, WIND_SHEAR, PAT>(a, vec, svec, grid, s, t0, t1);
-    case WIND_TABLE: return launch_vec<T, MISSION, WIND_TABLE, PAT>(a, vec, svec, grid, s, t0, t1);
-    case WIND_GRID:  return launch_vec<T, MISSION, WIND_GRID, PAT>(a, vec, svec, grid, s, t0, t1);
+    case WIND_NONE:  return launch_vec<T, MISSION, WIND_NONE, PAT>(a, vec, grid, s, t0, t1);
+    case WIND_SHEAR: return launch_vec<T, MISSION, WIND_SHEAR, PAT>(a, vec, grid, s, t0, t1);
+    case WIND_TABLE: return launch_vec<T, MISSION, WIND_TABLE, PAT>(a, vec, grid, s, t0, t1);
+    case WIND_GRID:  return launch_vec<T, MISSION, WIND_GRID, PAT>(a, vec, grid, s, t0, t1);
     }
     return hipErrorInvalidValue;
 }
 
 template <typename T, int PAT>
-hipError_t launch_mission(const FgArgs &a, int mission, int wind, int vec, int svec, dim3 grid, hipStream_t s, hipEvent_t t0,
+hipError_t launch_mission(const FgArgs &a, int mission, int wind, int vec, dim3 grid, hipStream_t s, hipEvent_t t0,
                           hipEvent_t t1)
 {
     switch (mission) {
-    case MISSION_S10:   return launch_wind<T, MISSION_S10, PAT>(a, wind, vec, svec, grid, s, t0, t1);
-    case MISSION_G7:    return launch_wind<T, MISSION_G7, PAT>(a, wind, vec, svec, grid, s, t0, t1);
-    case MISSION_MIXED: return launch_wind<T, MISSION_MIXED, PAT>(a, wind, vec, svec, grid, s, t0, t1);
+    case MISSION_S10:   return launch_wind<T, MISSION_S10, PAT>(a, wind, vec, grid, s, t0, t1);
+    case MISSION_G7:    return launch_wind<T, MISSION_G7, PAT>(a, wind, vec, grid, s, t0, t1);
+    case MISSION_MIXED: return launch_wind<T, MISSION_MIXED, PAT>(a, wind, vec, grid, s, t0, t1);
     }
     return hipErrorInvalidValue;
 }
@@ -1040,7 +1076,7 @@ __global__ void bounds_kernel(const BoundsArgs a)
 
 }  // namespace
 
-hipError_t launch_fg(const FgArgs &a, int mission, int wind, int dtype, int vec, int svec, hipStream_t s, hipEvent_t t0,
+hipError_t launch_fg(const FgArgs &a, int mission, int wind, int dtype, int vec, hipStream_t s, hipEvent_t t0,
                      hipEvent_t t1)
 {
     if (a.B <= 0) return hipSuccess;
@@ -1054,11 +1090,11 @@ hipError_t launch_fg(const FgArgs &a, int mission, int wind, int dtype, int vec,
     if (a.xcd_chunk != 0 && a.xcd_chunk != (int)((W + 7) / 8)) return hipErrorInvalidValue;
     const dim3 grid((unsigned)(a.xcd_chunk > 0 ? 8L * a.xcd_chunk : W));
     if (a.pattern == PATTERN_COMPACT) {
-        return dtype == 0 ? launch_mission<double, PATTERN_COMPACT>(a, mission, wind, vec, svec, grid, s, t0, t1)
-                          : launch_mission<float, PATTERN_COMPACT>(a, mission, wind, vec, svec, grid, s, t0, t1);
+        return dtype == 0 ? launch_mission<double, PATTERN_COMPACT>(a, mission, wind, vec, grid, s, t0, t1)
+                          : launch_mission<float, PATTERN_COMPACT>(a, mission, wind, vec, grid, s, t0, t1);
     }
-    return dtype == 0 ? launch_mission<double, PATTERN_REFERENCE>(a, mission, wind, vec, svec, grid, s, t0, t1)
-                      : launch_mission<float, PATTERN_REFERENCE>(a, mission, wind, vec, svec, grid, s, t0, t1);
+    return dtype == 0 ? launch_mission<double, PATTERN_REFERENCE>(a, mission, wind, vec, grid, s, t0, t1)
+                      : launch_mission<float, PATTERN_REFERENCE>(a, mission, wind, vec, grid, s, t0, t1);
 }
 
 hipError_t launch_objectives(const void *F, long ldf, void *obj, int B, int dtype, hipStream_t s)

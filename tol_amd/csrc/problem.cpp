@@ -294,17 +294,12 @@ void batch::eval(int B, const void *dX, long ldx, void *dF, long ldf, void *dG, 
     a.X = dX; a.ldx = ldx; a.F = dF; a.ldf = ldf; a.G = dG; a.ldg = ldg;
     a.wind = dWind; a.traj = d_traj_;
     a.B = B; a.needF = needF ? 1 : 0; a.needG = needG ? 1 : 0;
-    // 16-byte accesses need every row's x window on a 16-byte boundary; the slab stores are as wide as
-    // every slab region's alignment allows (c0 of every mission in the batch)
+    // 16-byte window loads and defect stores need the rows of X and F on 16-byte boundaries; the slab stream
+    // copes with any position of G (the waves shift their streams)
     const int vmax = dtype_ == TOLFG_F64 ? 2 : 4;
     const bool aligned = (reinterpret_cast<uintptr_t>(dX) % 16 == 0) && (ldx % vmax == 0) &&
-                         (!needF || ((reinterpret_cast<uintptr_t>(dF) % 16 == 0) && (ldf % vmax == 0))) &&
-                         (!needG || ((reinterpret_cast<uintptr_t>(dG) % 16 == 0) && (ldg % vmax == 0)));
-    int vec = aligned ? vmax : 1, svec = vec;
-    for (int m = 0; m < 2; ++m)
-        if (mission_ == MISSION_MIXED || m == mission_)
-            while (svec > 1 && szm_[m].c0 % svec != 0) svec >>= 1;
-    if (svec != vec && !(dtype_ == TOLFG_F32 && vec == 4 && svec == 2 && !a.single)) vec = svec = 1;   // the kernel pairs that exist
+                         (!needF || ((reinterpret_cast<uintptr_t>(dF) % 16 == 0) && (ldf % vmax == 0)));
+    const int vec = aligned ? vmax : 1;
     hipEvent_t t0 = nullptr, t1 = nullptr;
     if (timing_) {                 // HIP events on the launch stream, around the whole evaluation
         if (ev_used_ + 2 > ev_.size()) {
@@ -315,7 +310,7 @@ void batch::eval(int B, const void *dX, long ldx, void *dF, long ldf, void *dG, 
         t0 = ev_[ev_used_++];
         t1 = ev_[ev_used_++];
     }
-    check(launch_fg(a, mission_, kernel_wind(windmodel_), dtype_, vec, svec, stream, t0, t1), "launch fg");
+    check(launch_fg(a, mission_, kernel_wind(windmodel_), dtype_, vec, stream, t0, t1), "launch fg");
 }
 
 void batch::set_timing(bool on)

@@ -144,16 +144,6 @@ tolfg::FgArgs make_args(Buffers &bf, int max_nt, int cap, int fused, int xi, voi
     return a;
 }
 
-// widest slab store the slab regions of this shape are aligned for (c0 of every mission present)
-int slab_vec(const Shape &sh)
-{
-    int sv = sh.dtype == 0 ? 2 : 4;
-    for (int m = 0; m < 2; m++)
-        if (sh.mission == tolfg::MISSION_MIXED || sh.mission == m)
-            while (sv > 1 && (m == 0 ? 3 * sh.N + 4 : sh.N + 6) % sv) sv >>= 1;
-    return sv;
-}
-
 long compare(const Buffers &bf)
 {
     const Shape &sh = bf.sh;
@@ -204,25 +194,25 @@ int main(int argc, char **argv)
             bf.nt = 1; bf.xcd = 0;
             tolfg::FgArgs r = make_args(bf, 64, 0, 0, 0, bf.dF2, bf.dG2);     // reference result of this shape
             bf.nt = nt_keep; bf.xcd = xcd_keep;
-            CK(tolfg::launch_fg(r, sh.mission, tolfg::WIND_SHEAR, sh.dtype, sh.dtype == 0 ? 2 : 4, slab_vec(sh), st));
+            CK(tolfg::launch_fg(r, sh.mission, tolfg::WIND_SHEAR, sh.dtype, sh.dtype == 0 ? 2 : 4, st));
             CK(hipStreamSynchronize(st));
         }
         const int vec = sh.dtype == 0 ? 2 : 4;
         tolfg::FgArgs a = make_args(bf, v[2], v[3], v[4], 0, bf.dF, bf.dG);
         CK(hipMemsetAsync(bf.dF, 0xff, bf.es() * sh.B * sh.ldf, st));
         CK(hipMemsetAsync(bf.dG, 0xff, bf.es() * sh.B * sh.ldg, st));
-        CK(tolfg::launch_fg(a, sh.mission, tolfg::WIND_SHEAR, sh.dtype, vec, slab_vec(sh), st));
+        CK(tolfg::launch_fg(a, sh.mission, tolfg::WIND_SHEAR, sh.dtype, vec, st));
         CK(hipStreamSynchronize(st));
         const long bad = compare(bf);
         for (int w = 0; w < 5; w++) {
             tolfg::FgArgs aw = make_args(bf, v[2], v[3], v[4], w, bf.dF, bf.dG);
-            CK(tolfg::launch_fg(aw, sh.mission, tolfg::WIND_SHEAR, sh.dtype, vec, slab_vec(sh), st));
+            CK(tolfg::launch_fg(aw, sh.mission, tolfg::WIND_SHEAR, sh.dtype, vec, st));
         }
         CK(hipStreamSynchronize(st));
         CK(hipEventRecord(e0, st));
         for (int r = 0; r < reps; r++) {
             tolfg::FgArgs ar = make_args(bf, v[2], v[3], v[4], r, bf.dF, bf.dG);
-            CK(tolfg::launch_fg(ar, sh.mission, tolfg::WIND_SHEAR, sh.dtype, vec, slab_vec(sh), st));
+            CK(tolfg::launch_fg(ar, sh.mission, tolfg::WIND_SHEAR, sh.dtype, vec, st));
         }
         CK(hipEventRecord(e1, st));
         CK(hipEventSynchronize(e1));
@@ -231,7 +221,7 @@ int main(int argc, char **argv)
         // repeat of the check after the timed launches: the counters must have been left at zero
         CK(hipMemsetAsync(bf.dF, 0xff, bf.es() * sh.B * sh.ldf, st));
         CK(hipMemsetAsync(bf.dG, 0xff, bf.es() * sh.B * sh.ldg, st));
-        CK(tolfg::launch_fg(a, sh.mission, tolfg::WIND_SHEAR, sh.dtype, vec, slab_vec(sh), st));
+        CK(tolfg::launch_fg(a, sh.mission, tolfg::WIND_SHEAR, sh.dtype, vec, st));
         CK(hipStreamSynchronize(st));
         const long bad2 = compare(bf);
         const long neG_eff = bf.pat == tolfg::PATTERN_COMPACT ? sh.c0 + 46L * sh.N + (sh.mission == tolfg::MISSION_G7 ? 30 : 22) : sh.neG;

@@ -74,10 +74,10 @@ int main(int argc, char **argv)
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     if (variant & 8192) a.needF = 0;
-    for (int i = 0; i < 5; i++) CK(tolfg::launch_fg(a, tolfg::MISSION_S10, tolfg::WIND_SHEAR, 0, 2, 2, nullptr));
+    for (int i = 0; i < 5; i++) CK(tolfg::launch_fg(a, tolfg::MISSION_S10, tolfg::WIND_SHEAR, 0, 2, nullptr));
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0));
-    for (int i = 0; i < reps; i++) CK(tolfg::launch_fg(a, tolfg::MISSION_S10, tolfg::WIND_SHEAR, 0, 2, 2, nullptr));
+    for (int i = 0; i < reps; i++) CK(tolfg::launch_fg(a, tolfg::MISSION_S10, tolfg::WIND_SHEAR, 0, 2, nullptr));
     CK(hipEventRecord(e1));
     CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
