@@ -126,9 +126,9 @@ struct BoundsArgs {
 hipError_t launch_bounds(const BoundsArgs &a, int dtype, hipStream_t s);
 
 // LDS bytes per workgroup of the fg kernel (for DESIGN.md / occupancy reporting)
-int fg_lds_bytes(int dtype);
+int fg_lds_bytes(int dtype, int nt = 0);        // nt = nodes per tile (0 = 64)
 // LDS bytes to request at launch so that at most waves_per_cu workgroups share a CU (0 = no cap)
-int fg_lds_request(int dtype, int waves_per_cu);
+int fg_lds_request(int dtype, int waves_per_cu, int nt = 0);
 
 }  // namespace tolfg
 #endif

@@ -579,15 +579,18 @@ __device__ __forceinline__ void tile_body(const FgArgs &a, T *lds, int item, int
     pub.arrive(lane, a.needF != 0, (double)sumT, (double)sumP);
 
     if (a.needG) {
-        T *row = lds + lane * RS;
+        // idle lanes (lane >= cnt) leave no row: the workgroup's LDS holds a.nt rows, not TILE
+        if (act) {
+            T *row = lds + lane * RS;
 #ifdef TOLFG_STAMPS
-        if (TOLFG_VARIANT(a) & 256) {
+            if (TOLFG_VARIANT(a) & 256) {
 #pragma unroll
-            for (int i = 0; i < 32; i++) row[i] = s[i % NI];
-        } else
+                for (int i = 0; i < 32; i++) row[i] = s[i % NI];
+            } else
 #endif
-        nc.jacobian(f, row);
-        row[SL_ZERO] = T(0); row[SL_ONE] = T(1); row[SL_MONE] = T(-1);
+            nc.jacobian(f, row);
+            row[SL_ZERO] = T(0); row[SL_ONE] = T(1); row[SL_MONE] = T(-1);
+        }
         __syncthreads();
         TOLFG_STAMP(a, 3);
         __builtin_amdgcn_sched_barrier(0);
@@ -907,7 +910,7 @@ hipError_t launch_vec(const FgArgs &a, int vec, dim3 grid, hipStream_t s, hipEve
     // Timing events ride on the dispatches themselves (hipExtLaunchKernelGGL: the kernel's own start / end
     // timestamps, no extra commands on the stream): t0 = start of fg_kernel, t1 = end of the evaluation's
     // last kernel (fg_kernel when fused, else finalize_kernel).
-    const unsigned lds = (unsigned)fg_lds_request(sizeof(T) == 8 ? 0 : 1, a.waves_per_cu);
+    const unsigned lds = (unsigned)fg_lds_request(sizeof(T) == 8 ? 0 : 1, a.waves_per_cu, a.nt);
     hipEvent_t fg_end = a.fused ? t1 : nullptr;
     auto go = [&](auto kernel, dim3 g, unsigned ldsz, hipEvent_t st, hipEvent_t en) {
         if (st || en) hipExtLaunchKernelGGL(kernel, g, dim3(TILE), ldsz, s, st, en, 0, a);
@@ -1136,12 +1139,17 @@ hipError_t launch_bounds(const BoundsArgs &a, int dtype, hipStream_t s)
     return hipGetLastError();
 }
 
-int fg_lds_bytes(int dtype) { return TILE * RS * (dtype == 0 ? 8 : 4); }
+int fg_lds_bytes(int dtype, int nt)
+{
+    // nt rows of RS elements (the x window, 11*nt + 10 elements at most, is staged in the same space first)
+    const int rows = nt > 0 && nt < TILE ? nt : TILE;
+    return ((rows * RS * (dtype == 0 ? 8 : 4)) + 15) & ~15;
+}
 
-int fg_lds_request(int dtype, int waves_per_cu)
+int fg_lds_request(int dtype, int waves_per_cu, int nt)
 {
     // LDS per workgroup such that at most `waves_per_cu` one-wave workgroups fit the CU's 160 KiB
-    const int need = fg_lds_bytes(dtype);
+    const int need = fg_lds_bytes(dtype, nt);
     if (waves_per_cu <= 0) return need;
     int cap = (160 * 1024 / waves_per_cu) & ~15;
     if (cap > 64 * 1024) cap = 64 * 1024;

@@ -176,7 +176,7 @@ int main(int argc, char **argv)
     CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    printf("| B | N | mission | dtype | max_nt -> tiles x nt | cap | fused | us/eval | GB/s alg | %% of 8 TB/s | check |\n|---|---|---|---|---|---|---|---|---|---|---|\n");
+    printf("| B | N | mission | dtype | max_nt -> tiles x nt | cap | fused | us/eval back to back | kernel us (dispatch events) | GB/s alg | %% of 8 TB/s | check |\n|---|---|---|---|---|---|---|---|---|---|---|---|\n");
     for (int i = 1; i < argc; i++) {
         if (!strncmp(argv[i], "reps=", 5)) { reps = atoi(argv[i] + 5); continue; }
         if (!strncmp(argv[i], "xbuf=", 5)) { xbuf = atoi(argv[i] + 5); bf.release(); bf.sh = Shape{}; continue; }
@@ -209,15 +209,19 @@ int main(int argc, char **argv)
             CK(tolfg::launch_fg(aw, sh.mission, tolfg::WIND_SHEAR, sh.dtype, vec, st));
         }
         CK(hipStreamSynchronize(st));
+        static std::vector<hipEvent_t> kev;                 // per-launch events riding on the dispatches
+        while ((int)kev.size() < 2 * reps) { hipEvent_t e; CK(hipEventCreate(&e)); kev.push_back(e); }
         CK(hipEventRecord(e0, st));
         for (int r = 0; r < reps; r++) {
             tolfg::FgArgs ar = make_args(bf, v[2], v[3], v[4], r, bf.dF, bf.dG);
-            CK(tolfg::launch_fg(ar, sh.mission, tolfg::WIND_SHEAR, sh.dtype, vec, st));
+            CK(tolfg::launch_fg(ar, sh.mission, tolfg::WIND_SHEAR, sh.dtype, vec, st, kev[2 * r], kev[2 * r + 1]));
         }
         CK(hipEventRecord(e1, st));
         CK(hipEventSynchronize(e1));
         float ms;
         CK(hipEventElapsedTime(&ms, e0, e1));
+        double kern_us = 0;
+        for (int r = 0; r < reps; r++) { float k; CK(hipEventElapsedTime(&k, kev[2 * r], kev[2 * r + 1])); kern_us += 1e3 * k / reps; }
         // repeat of the check after the timed launches: the counters must have been left at zero
         CK(hipMemsetAsync(bf.dF, 0xff, bf.es() * sh.B * sh.ldf, st));
         CK(hipMemsetAsync(bf.dG, 0xff, bf.es() * sh.B * sh.ldg, st));
@@ -227,9 +231,9 @@ int main(int argc, char **argv)
         const long neG_eff = bf.pat == tolfg::PATTERN_COMPACT ? sh.c0 + 46L * sh.N + (sh.mission == tolfg::MISSION_G7 ? 30 : 22) : sh.neG;
         const double bytes = (double)bf.es() * sh.B * ((double)sh.n + sh.neF + neG_eff);
         const double us = 1e3 * ms / reps;
-        printf("| %d | %d | %s | %s | %d -> %d x %d | %d | %d%s%s | %.2f | %.0f | %.1f | %s |\n", sh.B, sh.N,
+        printf("| %d | %d | %s | %s | %d -> %d x %d | %d | %d%s%s | %.2f | %.2f | %.0f | %.1f | %s |\n", sh.B, sh.N,
                sh.mission == 0 ? "S10" : (sh.mission == 1 ? "G7" : "mixed"), sh.dtype == 0 ? "f64" : "f32", v[2], a.tiles, a.nt, v[3], v[4],
-               bf.nt ? " nt" : " plain", bf.xcd ? " xcd" : "", us,
+               bf.nt ? " nt" : " plain", bf.xcd ? " xcd" : "", us, kern_us,
                bytes / (1e3 * us), 100.0 * bytes / (1e3 * us) / 8000.0, (bad || bad2) ? "MISMATCH" : "ok");
         fflush(stdout);
     }

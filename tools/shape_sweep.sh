@@ -1,10 +1,10 @@
 #!/bin/bash
 # throughput across problem shapes (not the headline; for the record)
-run() { timeout -k 10 200 python bench.py --steps 60 --warmup 5 --no-cpu-baseline --no-configs "$@" 2>&1 | tail -1 | python3 -c "
+run() { timeout -k 10 200 python bench.py --steps 60 --warmup 5 --no-cpu-baseline --no-configs "$@" 2>/dev/null | tail -1 | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read()); c=d['config']; r=d['roofline']
 print('| %s | %s | %d | %d | %s | %s | %.3g | %.0f | %.1f |' % (c['mission'], c['aircraft'], c['ts'], c['batch_per_gpu'], d['dtype'], c['pattern'], d['value'], r['achieved'], 100*r['frac']))"; }
-echo "| mission | air-frame | ts | batch | dtype | pattern | node-evals/s | fg_kernel GB/s | % of 8 TB/s |"
+echo "| mission | air-frame | ts | batch | dtype | pattern | node-evals/s (whole step) | evaluation GB/s | % of 8 TB/s |"
 echo "|---|---|---|---|---|---|---|---|---|"
 run --ts 100 --batch 8192
 run --ts 200 --batch 4096
@@ -20,3 +20,9 @@ run --ts 200 --batch 4096 --dtype f32
 run --ts 200 --batch 4096 --pattern compact
 run --ts 2000 --batch 400 --pattern compact --aircraft skywalker
 run --mission G7 --ts 200 --batch 4096 --pattern compact --dtype f32
+run --ts 200 --batch 256
+run --ts 200 --batch 128
+run --mission mixed --ts 200 --batch 8192
+run --mission mixed --ts 200 --batch 8192 --dtype f32
+run --mission G7 --ts 200 --batch 4096 --dtype f32
+run --ts 201 --batch 4096
