@@ -10,6 +10,7 @@ enum { MISSION_S10 = 0, MISSION_G7 = 1, MISSION_MIXED = 2 };   // MIXED: every t
 enum { WIND_NONE = 0, WIND_SHEAR = 1, WIND_TABLE = 2, WIND_GRID = 3 };   // kernel-side enumeration
 enum { MAX_AIRCRAFT = 8 };
 enum { PATTERN_REFERENCE = 0, PATTERN_COMPACT = 1 };   // slab_table.h
+enum { QUEUE_STRIDE = 1024, QUEUE_WORDS = 33 * 1024 };  // unsigned words between the tile-queue heads (4 KiB); size of the array
 constexpr unsigned kEmptySlotWord = 0xFFFBADADu;        // fused path: every 32-bit word of an empty partial slot
 
 // Air-frame constants as the kernels want them (reciprocals taken once on the host).
@@ -67,11 +68,16 @@ struct FgArgs {
     int  fused;            // 1 = the tile wave that arrives last at its trajectory's counter finalizes (one launch);
                            // 0 = finalize_kernel follows fg_kernel
     int  nt_stores;        // 1 = the slab stream carries the non-temporal hint (outputs beyond the Infinity Cache)
-    int  xcd_chunk;        // > 0: ceil(B*tiles/8), workgroup id -> tile (id % 8) * xcd_chunk + id / 8; 0: id -> tile id
+    int  xcd_chunk;        // workgroup id < 8 * xcd_chunk -> tile (id % 8) * xcd_chunk + id / 8 (every XCD walks a contiguous
+                           // run of xcd_chunk tiles); id >= 8 * xcd_chunk -> tile id.  0 <= xcd_chunk <= ceil(B*tiles/8)
+    int  persist;          // experiment only (TOLFG_PERSIST_EXPERIMENT builds): persist_groups workgroups walk the tiles
+                           // through per-XCD queues; the product build refuses it
+    int  persist_groups;
     double *partial;       // [B*tiles][2] objective partials (sum T^2, sum (r-R)^2), device; on the fused path
                            // every slot is "empty" (kEmptySlotWord) between launches
-    unsigned *counter;     // [B + 1] arrival counters of the fused path ([B]: departures, below): zero before a
-                           // launch, reset by the wave that saw the last arrival
+    unsigned *counter;     // [B + 1]: [0, B) arrival counters of the fused path, [B] departures of the callback's
+                           // completion word; all zero before a launch, put back to zero by the launch itself
+    unsigned *queues;      // persistent form: QUEUE_WORDS words (32 queue heads + departures, QUEUE_STRIDE apart), zero between launches
     // Completion word for the SNOPT callback (host-mapped, or nullptr): when every wave's stores are visible
     // to the host, the last wave to leave writes done_seq there, so the caller can spin on it instead of
     // synchronising the stream.

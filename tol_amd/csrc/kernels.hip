@@ -83,8 +83,15 @@ constexpr int gcd_c(int a, int b) { return b == 0 ? a : gcd_c(b, a % b); }
         asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                \
         if (threadIdx.x == 0) (a).stamps[(size_t)blockIdx.x * 10 + (slot)] = t_;                     \
     } while (0)
+#define TOLFG_WHERE(a, slot)                                                                         \
+    do {                                                                                             \
+        unsigned hw_, xcc_;                                                                          \
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hw_), "=s"(xcc_)); \
+        if (threadIdx.x == 0) (a).stamps[(size_t)blockIdx.x * 10 + (slot)] = ((unsigned long long)xcc_ << 32) | hw_;     \
+    } while (0)
 #define TOLFG_VARIANT(a) ((a).variant)
 #else
+#define TOLFG_WHERE(a, slot) do {} while (0)
 #define TOLFG_STAMP(a, slot) do {} while (0)
 #define TOLFG_REALTIME(a, slot) do {} while (0)
 #define TOLFG_VARIANT(a) 0
@@ -467,8 +474,14 @@ struct Publish {
 
 // One tile: everything a wavefront does for `cnt` consecutive nodes of trajectory b.  lds is the
 // wave's own TILE*RS-element region; sumT / sumP return the tile's objective terms (wave-uniform).
-template <typename T, int MISSION, int WIND, int VEC, int PAT, bool NT>
-__device__ __forceinline__ void tile_body(const FgArgs &a, T *lds, int item, int lane, T &sumT_out, T &sumP_out, Publish &pub)
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
+
+// `after_window` runs once the x window has been consumed (the wave's loads are back): the persistent form
+// asks for its next tile there, so that the atomic's round trip hides behind the arithmetic and the stores
+// instead of sitting in front of the window loads (vmcnt counts in order).
+template <typename T, int MISSION, int WIND, int VEC, int PAT, bool NT, typename Hook = NoHook>
+__device__ __forceinline__ void tile_body(const FgArgs &a, T *lds, int item, int lane, T &sumT_out, T &sumP_out, Publish &pub,
+                                          Hook after_window = Hook())
 {
     typedef typename Vec<T, VEC>::type vec;
     // slab stores: 16 bytes per lane whatever the region's alignment (stream_slabs shifts the stream), where
@@ -488,6 +501,7 @@ __device__ __forceinline__ void tile_body(const FgArgs &a, T *lds, int item, int
     // aligned) up to the 8 states of node k0+cnt, rounded up to whole vectors (stays inside the row);
     // contiguous 16-byte loads -> LDS -> this lane's node (transpose)
     TOLFG_REALTIME(a, 7);
+    TOLFG_WHERE(a, 9);
     TOLFG_STAMP(a, 0);
     {
         const int nvec = (NI * cnt + 9 + VEC - 1) / VEC;
@@ -531,6 +545,7 @@ __device__ __forceinline__ void tile_body(const FgArgs &a, T *lds, int item, int
     }
     __syncthreads();                           // the rows below overwrite the window
     TOLFG_STAMP(a, 2);
+    after_window();
 
     const AcCoef &ac = a.ac[tr.ac];
     T f[8];
@@ -784,24 +799,10 @@ __device__ __forceinline__ void sum_partials(const double *part, int tiles, int 
     sumP = wave_sum(sp);
 }
 
-// fg_kernel: one 64-lane workgroup per tile.  Workgroup ids go round-robin over the 8 XCDs; with
-// a.xcd_chunk > 0 workgroup id works on tile (id % 8) * xcd_chunk + id / 8, so that every XCD walks
-// its own contiguous eighth of the batch's memory (measured +6 % on the write stream,
-// profiles/r02_write_shapes.md); otherwise consecutive workgroups walk the memory in order.
-// Fused form (a.fused): the wave that arrives last at its trajectory's counter also finalizes it, so
-// an evaluation is one launch; otherwise finalize_kernel follows.
-template <typename T, int MISSION, int WIND, int VEC, int PAT, bool NT>
-__global__ __launch_bounds__(TILE, TOLFG_MIN_WAVES_PER_SIMD) void fg_kernel(const FgArgs a)
+// One tile and, on the fused path, the finalization of its trajectory when this wave arrived last.
+template <typename T, int MISSION, int WIND, int VEC, int PAT, bool NT, typename Hook = NoHook>
+__device__ __forceinline__ void run_tile(const FgArgs &a, T *lds, int item, int lane, Hook after_window = Hook())
 {
-    // dynamic LDS: TILE*RS elements are used; the launch may request more to cap the waves per CU
-    // (fewer concurrent store streams suit the HBM write path better, DESIGN.md section 6)
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    const int lane = threadIdx.x;
-    int item = blockIdx.x;
-    if (a.xcd_chunk > 0) {
-        item = (item & 7) * a.xcd_chunk + (item >> 3);
-        if (item >= a.B * a.tiles) return;         // the grid is rounded up to 8 * xcd_chunk
-    }
     const int b = item / a.tiles;
     T sumT, sumP;
     Publish pub{nullptr, nullptr, 0u};
@@ -809,7 +810,7 @@ __global__ __launch_bounds__(TILE, TOLFG_MIN_WAVES_PER_SIMD) void fg_kernel(cons
         pub.slot = a.partial + 2 * (long)item;
         pub.counter = a.counter + b;
     }
-    tile_body<T, MISSION, WIND, VEC, PAT, NT>(a, reinterpret_cast<T *>(lds_raw), item, lane, sumT, sumP, pub);
+    tile_body<T, MISSION, WIND, VEC, PAT, NT>(a, lds, item, lane, sumT, sumP, pub, after_window);
     if (a.fused) {
         const unsigned old = __builtin_amdgcn_readfirstlane(pub.old);
         if (old == (unsigned)(a.tiles - 1)) {          // wave-uniform: every tile of b has arrived
@@ -822,7 +823,106 @@ __global__ __launch_bounds__(TILE, TOLFG_MIN_WAVES_PER_SIMD) void fg_kernel(cons
         a.partial[2 * (long)item + 0] = (double)sumT;
         a.partial[2 * (long)item + 1] = (double)sumP;
     }
-    if (a.done) signal_done(a, a.B * a.tiles, lane == 0);
+}
+
+#ifdef TOLFG_PERSIST_EXPERIMENT      // measured and not adopted (profiles/r02_persistent.md); built by tools/fgbench.cpp only
+// Persistent form: the tiles of the batch are cut into 8 contiguous chunks, one per XCD, and each chunk into
+// 4 sub-chunks with a queue head each (32 heads, one per 4 KiB: same-address device atomics run at only
+// ~15-20 M/s, so 8 heads in one line made this form 2x slower and 8 heads on 8 lines still 10 % slower than
+// one workgroup per tile).  The workgroups -- as many as fit the machine at once -- take tiles from a
+// sub-chunk of the XCD they run on, then from its siblings, then from the other XCDs.  Nobody waits.
+struct TileQueues {
+    enum { NQ = 32 };
+    unsigned *head;        // head[q * QUEUE_STRIDE], q < NQ; departures at head[NQ * QUEUE_STRIDE]; zero between launches
+    int xchunk, sub;       // tiles per XCD chunk = ceil(W / 8), per sub-chunk = ceil(xchunk / 4)
+    long W;
+    __device__ __forceinline__ long start(int q) const { return (long)(q >> 2) * xchunk + (long)(q & 3) * sub; }
+    __device__ __forceinline__ int len(int q) const
+    {
+        long end = start(q) + sub;
+        const long xend = (long)((q >> 2) + 1) * xchunk;
+        end = end < xend ? end : xend;
+        end = end < W ? end : W;
+        const long n = end - start(q);
+        return n > 0 ? (int)n : 0;
+    }
+    // position in queue q (lane 0 holds it; a position >= len(q) means "empty")
+    __device__ __forceinline__ unsigned take(int q, int lane) const
+    {
+        unsigned pos = 0;
+        if (lane == 0) pos = __hip_atomic_fetch_add(head + q * QUEUE_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return pos;
+    }
+    // a queue that still has tiles: the siblings of q first, then the other XCDs' queues; -1 when all are empty
+    __device__ __forceinline__ int other(int q, int lane) const
+    {
+        unsigned h = 0xffffffffu;
+        if (lane < NQ) h = __hip_atomic_load(head + lane * QUEUE_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int i = 1; i < 4; i++) {
+            const int c = (q & ~3) | ((q + i) & 3);
+            if ((unsigned)__builtin_amdgcn_readlane((int)h, c) < (unsigned)len(c)) return c;
+        }
+        for (int i = 4; i < NQ; i++) {
+            const int c = ((q & ~3) + i) & (NQ - 1);
+            if ((unsigned)__builtin_amdgcn_readlane((int)h, c) < (unsigned)len(c)) return c;
+        }
+        return -1;
+    }
+};
+#endif
+
+// fg_kernel: one 64-lane workgroup per tile.  Workgroup ids go round-robin over the 8 XCDs; with
+// a.xcd_chunk > 0 workgroup id works on tile (id % 8) * xcd_chunk + id / 8, so that every XCD walks
+// its own contiguous eighth of the batch's memory (measured +6 % on the write stream,
+// profiles/r02_write_shapes.md); otherwise consecutive workgroups walk the memory in order.
+// (With TOLFG_PERSIST_EXPERIMENT and a.persist the grid is only as large as the machine holds and every workgroup
+// walks tiles of its XCD's chunk, TileQueues: 12-25 % slower, profiles/r02_persistent.md.)
+// Fused form (a.fused): the wave that arrives last at its trajectory's counter also finalizes it, so
+// an evaluation is one launch; otherwise finalize_kernel follows.
+template <typename T, int MISSION, int WIND, int VEC, int PAT, bool NT>
+__global__ __launch_bounds__(TILE, TOLFG_MIN_WAVES_PER_SIMD) void fg_kernel(const FgArgs a)
+{
+    // dynamic LDS: nt*RS elements are used; the launch may request more to cap the waves per CU
+    // (fewer concurrent store streams suit the HBM write path better, DESIGN.md section 6)
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    T *lds = reinterpret_cast<T *>(lds_raw);
+    const int lane = threadIdx.x;
+#ifdef TOLFG_PERSIST_EXPERIMENT
+    if (!a.persist)
+#endif
+    {
+        int item = blockIdx.x;
+        if (item < 8 * a.xcd_chunk) item = (item & 7) * a.xcd_chunk + (item >> 3);     // the rest (the launch's tail) in id order
+        if (item >= a.B * a.tiles) return;             // the grid may be rounded up to 8 * xcd_chunk
+        run_tile<T, MISSION, WIND, VEC, PAT, NT>(a, lds, item, lane);
+        if (a.done) signal_done(a, a.B * a.tiles, lane == 0);
+        return;
+    }
+#ifdef TOLFG_PERSIST_EXPERIMENT
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    const TileQueues q{a.queues, a.xcd_chunk, (a.xcd_chunk + 3) / 4, (long)a.B * a.tiles};
+    int mine = (int)(xcc & 7) * 4 + (int)((blockIdx.x >> 3) & 3);
+    unsigned pos = q.take(mine, lane);
+    for (long guard = 0; guard <= q.W; guard++) {            // every pass takes a tile or leaves
+        unsigned p = (unsigned)__builtin_amdgcn_readfirstlane((int)pos);
+        while (p >= (unsigned)q.len(mine)) {                 // this chunk is empty: move to one that is not
+            mine = q.other(mine, lane);
+            if (mine < 0) break;
+            p = (unsigned)__builtin_amdgcn_readfirstlane((int)q.take(mine, lane));
+        }
+        if (mine < 0) break;
+        // the next tile's position is asked for once this tile's window is in: on its way while the tile is worked on
+        run_tile<T, MISSION, WIND, VEC, PAT, NT>(a, lds, (int)(q.start(mine) + p), lane, [&]() { pos = q.take(mine, lane); });
+        __syncthreads();                                     // the LDS rows are reused
+    }
+    // the last workgroup to leave puts the heads back to zero for the next launch
+    if (lane == 0) {
+        const unsigned gone = __hip_atomic_fetch_add(q.head + TileQueues::NQ * QUEUE_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (gone == gridDim.x - 1)
+            for (int k = 0; k <= TileQueues::NQ; k++) __hip_atomic_store(q.head + k * QUEUE_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#endif
 }
 
 template <typename T, int MISSION, int PAT>
@@ -919,9 +1019,8 @@ hipError_t launch_vec(const FgArgs &a, int vec, dim3 grid, hipStream_t s, hipEve
     if (vec == VMAX) {
         if (a.nt_stores) go(fg_kernel<T, MISSION, WIND, VMAX, PAT, true>, grid, lds, t0, fg_end);
         else             go(fg_kernel<T, MISSION, WIND, VMAX, PAT, false>, grid, lds, t0, fg_end);
-    } else {              // rows of X or F off 16-byte boundaries: scalar window loads and defect stores
-        if (a.nt_stores) go(fg_kernel<T, MISSION, WIND, 1, PAT, true>, grid, lds, t0, fg_end);
-        else             go(fg_kernel<T, MISSION, WIND, 1, PAT, false>, grid, lds, t0, fg_end);
+    } else {              // rows of X or F off 16-byte boundaries: scalar window loads and defect stores (plain slab stores)
+        go(fg_kernel<T, MISSION, WIND, 1, PAT, false>, grid, lds, t0, fg_end);
     }
     e = hipGetLastError();
     if (e != hipSuccess) return e;
@@ -1079,6 +1178,27 @@ __global__ void bounds_kernel(const BoundsArgs a)
 
 }  // namespace
 
+// The evaluation kernels are instantiated per element type in two translation units so that the library builds in
+// parallel (csrc/Makefile: kernels.o with -DTOLFG_TU=0 holds fp64 and everything else, kernels_f32.o with
+// -DTOLFG_TU=1 the fp32 evaluation kernels); a build without TOLFG_TU (tools/fgbench.cpp) holds both.
+hipError_t launch_fg_f64(const FgArgs &a, int mission, int wind, int vec, dim3 grid, hipStream_t s, hipEvent_t t0, hipEvent_t t1);
+hipError_t launch_fg_f32(const FgArgs &a, int mission, int wind, int vec, dim3 grid, hipStream_t s, hipEvent_t t0, hipEvent_t t1);
+
+#if !defined(TOLFG_TU) || TOLFG_TU == 1
+hipError_t launch_fg_f32(const FgArgs &a, int mission, int wind, int vec, dim3 grid, hipStream_t s, hipEvent_t t0, hipEvent_t t1)
+{
+    return a.pattern == PATTERN_COMPACT ? launch_mission<float, PATTERN_COMPACT>(a, mission, wind, vec, grid, s, t0, t1)
+                                        : launch_mission<float, PATTERN_REFERENCE>(a, mission, wind, vec, grid, s, t0, t1);
+}
+#endif
+
+#if !defined(TOLFG_TU) || TOLFG_TU == 0
+hipError_t launch_fg_f64(const FgArgs &a, int mission, int wind, int vec, dim3 grid, hipStream_t s, hipEvent_t t0, hipEvent_t t1)
+{
+    return a.pattern == PATTERN_COMPACT ? launch_mission<double, PATTERN_COMPACT>(a, mission, wind, vec, grid, s, t0, t1)
+                                        : launch_mission<double, PATTERN_REFERENCE>(a, mission, wind, vec, grid, s, t0, t1);
+}
+
 hipError_t launch_fg(const FgArgs &a, int mission, int wind, int dtype, int vec, hipStream_t s, hipEvent_t t0,
                      hipEvent_t t1)
 {
@@ -1090,14 +1210,15 @@ hipError_t launch_fg(const FgArgs &a, int mission, int wind, int dtype, int vec,
     if (a.done && !a.fused && !a.single) return hipErrorInvalidValue;     // finalize_kernel would still be running
     const long W = (long)a.B * a.tiles;
     if (W > 0x7ffffff0L) return hipErrorInvalidValue;
-    if (a.xcd_chunk != 0 && a.xcd_chunk != (int)((W + 7) / 8)) return hipErrorInvalidValue;
-    const dim3 grid((unsigned)(a.xcd_chunk > 0 ? 8L * a.xcd_chunk : W));
-    if (a.pattern == PATTERN_COMPACT) {
-        return dtype == 0 ? launch_mission<double, PATTERN_COMPACT>(a, mission, wind, vec, grid, s, t0, t1)
-                          : launch_mission<float, PATTERN_COMPACT>(a, mission, wind, vec, grid, s, t0, t1);
-    }
-    return dtype == 0 ? launch_mission<double, PATTERN_REFERENCE>(a, mission, wind, vec, grid, s, t0, t1)
-                      : launch_mission<float, PATTERN_REFERENCE>(a, mission, wind, vec, grid, s, t0, t1);
+    if (a.xcd_chunk < 0 || a.xcd_chunk > (int)((W + 7) / 8)) return hipErrorInvalidValue;
+#ifdef TOLFG_PERSIST_EXPERIMENT
+    if (a.persist && (a.xcd_chunk <= 0 || a.persist_groups < 1 || a.done || !a.queues)) return hipErrorInvalidValue;
+#else
+    if (a.persist) return hipErrorInvalidValue;            // the persistent form is not part of the product build
+#endif
+    const long covered = 8L * a.xcd_chunk;
+    const dim3 grid((unsigned)(a.persist ? a.persist_groups : (covered > W ? covered : W)));
+    return dtype == 0 ? launch_fg_f64(a, mission, wind, vec, grid, s, t0, t1) : launch_fg_f32(a, mission, wind, vec, grid, s, t0, t1);
 }
 
 hipError_t launch_objectives(const void *F, long ldf, void *obj, int B, int dtype, hipStream_t s)
@@ -1155,5 +1276,6 @@ int fg_lds_request(int dtype, int waves_per_cu, int nt)
     if (cap > 64 * 1024) cap = 64 * 1024;
     return cap > need ? cap : need;
 }
+#endif   // TOLFG_TU != 1
 
 }  // namespace tolfg

@@ -4,7 +4,7 @@
 // a list of launch configurations back to back on one synthetic S10 or G7 batch, so that tile size,
 // waves-per-CU cap and the fused/unfused finalize can be compared inside ONE gpurun call:
 //
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o tools/bin/fgbench tools/fgbench.cpp
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o tools/bin/fgbench tools/fgbench.cpp      (add -DTOLFG_PERSIST_EXPERIMENT for persist=)
 //   tools/bin/fgbench [reps=N] [xbuf=K] [nt=0|1] [xcd=0|1] [pat=0|1] B,N,max_nt,cap,fused[,mission[,dtype]] ...
 //
 // Every configuration is first checked against the reference configuration of its shape
@@ -52,16 +52,16 @@ struct Buffers {
     void *dF = nullptr, *dG = nullptr, *dF2 = nullptr, *dG2 = nullptr;
     tolfg::TrajDev *dT = nullptr;
     double *dP = nullptr;
-    unsigned *dC = nullptr;
+    unsigned *dC = nullptr, *dQ = nullptr;
     long capW = 0, poll_ready = -1;
-    int nt = 1, xcd = 0, pat = 0;
+    int nt = 1, xcd = 0, pat = 0, persist = 0, xcdpct = 100;
     size_t es() const { return sh.dtype == 0 ? 8 : 4; }
     void release()
     {
         for (void *p : dX) (void)hipFree(p);
         dX.clear();
-        for (void *p : {dF, dG, dF2, dG2, (void *)dT, (void *)dP, (void *)dC}) if (p) (void)hipFree(p);
-        dF = dG = dF2 = dG2 = nullptr; dT = nullptr; dP = nullptr; dC = nullptr; capW = 0; poll_ready = -1;
+        for (void *p : {dF, dG, dF2, dG2, (void *)dT, (void *)dP, (void *)dC, (void *)dQ}) if (p) (void)hipFree(p);
+        dF = dG = dF2 = dG2 = nullptr; dT = nullptr; dP = nullptr; dC = nullptr; dQ = nullptr; capW = 0; poll_ready = -1;
     }
 };
 
@@ -109,8 +109,10 @@ void fill(Buffers &bf, const Shape &sh, int xbuf)
     CK(hipMemset(bf.dF2, 0xff, bf.es() * sh.B * sh.ldf));      // rows of a mixed batch leave their tails untouched
     CK(hipMemset(bf.dG2, 0xff, bf.es() * sh.B * sh.ldg));
     CK(hipMalloc(&bf.dT, sizeof(tolfg::TrajDev) * sh.B));
-    CK(hipMalloc(&bf.dC, sizeof(unsigned) * sh.B));
-    CK(hipMemset(bf.dC, 0, sizeof(unsigned) * sh.B));
+    CK(hipMalloc(&bf.dC, sizeof(unsigned) * (sh.B + 1)));
+    CK(hipMemset(bf.dC, 0, sizeof(unsigned) * (sh.B + 1)));
+    CK(hipMalloc(&bf.dQ, sizeof(unsigned) * tolfg::QUEUE_WORDS));
+    CK(hipMemset(bf.dQ, 0, sizeof(unsigned) * tolfg::QUEUE_WORDS));
     CK(hipMemcpy(bf.dT, tr.data(), sizeof(tolfg::TrajDev) * sh.B, hipMemcpyHostToDevice));
 }
 
@@ -127,8 +129,9 @@ tolfg::FgArgs make_args(Buffers &bf, int max_nt, int cap, int fused, int xi, voi
         CK(hipMalloc(&bf.dP, sizeof(double) * 2 * W));
         bf.capW = W;
     }
-    a.partial = bf.dP; a.counter = bf.dC; a.fused = fused; a.single = 0; a.obj = nullptr;
-    a.nt_stores = bf.nt; a.xcd_chunk = bf.xcd ? (int)((W + 7) / 8) : 0;
+    a.partial = bf.dP; a.counter = bf.dC; a.queues = bf.dQ; a.fused = fused; a.single = 0; a.obj = nullptr;
+    a.nt_stores = bf.nt; a.xcd_chunk = (bf.xcd || bf.persist) ? (int)((bf.persist ? W + 7 : W * bf.xcdpct / 100) / 8) : 0;
+    a.persist = (bf.persist > 0 && W > 256L * bf.persist) ? 1 : 0; a.persist_groups = 256 * bf.persist;
     if (fused && bf.poll_ready != W) {   // slots start empty; the unfused path leaves values behind
         CK(hipMemsetD32(reinterpret_cast<hipDeviceptr_t>(bf.dP), tolfg::kEmptySlotWord, 4 * (size_t)W));
         CK(hipDeviceSynchronize());
@@ -182,6 +185,8 @@ int main(int argc, char **argv)
         if (!strncmp(argv[i], "xbuf=", 5)) { xbuf = atoi(argv[i] + 5); bf.release(); bf.sh = Shape{}; continue; }
         if (!strncmp(argv[i], "nt=", 3)) { bf.nt = atoi(argv[i] + 3); continue; }
         if (!strncmp(argv[i], "xcd=", 4)) { bf.xcd = atoi(argv[i] + 4); continue; }
+        if (!strncmp(argv[i], "xcdpct=", 7)) { bf.xcdpct = atoi(argv[i] + 7); continue; }       // share of the tiles dealt XCD-contiguously
+        if (!strncmp(argv[i], "persist=", 8)) { bf.persist = atoi(argv[i] + 8); continue; }     // workgroups per CU, 0 = off
         if (!strncmp(argv[i], "pat=", 4)) { bf.pat = atoi(argv[i] + 4); bf.release(); bf.sh = Shape{}; continue; }
         int v[7] = {4096, 200, 64, 0, 0, 0, 0};
         int nv = 0;
@@ -233,7 +238,7 @@ int main(int argc, char **argv)
         const double us = 1e3 * ms / reps;
         printf("| %d | %d | %s | %s | %d -> %d x %d | %d | %d%s%s | %.2f | %.2f | %.0f | %.1f | %s |\n", sh.B, sh.N,
                sh.mission == 0 ? "S10" : (sh.mission == 1 ? "G7" : "mixed"), sh.dtype == 0 ? "f64" : "f32", v[2], a.tiles, a.nt, v[3], v[4],
-               bf.nt ? " nt" : " plain", bf.xcd ? " xcd" : "", us, kern_us,
+               bf.nt ? " nt" : " plain", a.persist ? " persist" : (bf.xcd ? (bf.xcdpct == 100 ? " xcd" : " xcd-part") : ""), us, kern_us,
                bytes / (1e3 * us), 100.0 * bytes / (1e3 * us) / 8000.0, (bad || bad2) ? "MISMATCH" : "ok");
         fflush(stdout);
     }

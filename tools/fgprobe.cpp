@@ -11,6 +11,7 @@
 #include "../tol_amd/csrc/plan.cpp"
 
 #include <algorithm>
+#include <map>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -47,11 +48,15 @@ int main(int argc, char **argv)
     double *dX, *dF, *dG; tolfg::TrajDev *dT; unsigned long long *dS;
     int tiles, nt;
     tolfg::plan_tiles(N, 0, 0, &tiles, &nt);
-    const int ipb = (variant & 255) > 0 ? (variant & 255) : 1;
+    const int ipb = 1;
     const long W = (long)B * tiles;
-    const long blocks = W; (void)ipb;
-    double *dP;
+    const int xcd = argc > 6 ? atoi(argv[6]) : 1, fused = argc > 7 ? atoi(argv[7]) : 1, nts = argc > 8 ? atoi(argv[8]) : 1;
+    const long blocks = xcd ? 8 * ((W + 7) / 8) : W;
+    double *dP; unsigned *dC;
     CK(hipMalloc(&dP, sizeof(double) * 2 * W));
+    CK(hipMemsetD32(reinterpret_cast<hipDeviceptr_t>(dP), tolfg::kEmptySlotWord, 4 * (size_t)W));
+    CK(hipMalloc(&dC, sizeof(unsigned) * (B + 1)));
+    CK(hipMemset(dC, 0, sizeof(unsigned) * (B + 1)));
     CK(hipMalloc(&dX, sizeof(double) * X.size()));
     CK(hipMalloc(&dF, sizeof(double) * B * ldf));
     CK(hipMalloc(&dG, sizeof(double) * B * ldg));
@@ -65,11 +70,12 @@ int main(int argc, char **argv)
     a.X = dX; a.ldx = ldx; a.F = dF; a.ldf = ldf; a.G = dG; a.ldg = ldg; a.wind = nullptr; a.traj = dT;
     a.B = B; a.N = N; a.tiles = tiles; a.nt = nt; a.partial = dP; a.obj = nullptr; a.c0[0] = 3 * N + 4; a.c0[1] = N + 6; a.needF = 1; a.needG = 1;
     a.kT[0] = 0; a.kp[0] = 8; a.kv[0] = 0; a.kdt[0] = 1;
-    a.nt_stores = 1;
+
     a.ac[0] = tolfg::AcCoef{1.0 / 6.1228, 1.2682 * 0.6316 / (2 * 6.1228), 0.03, 1.0 / (16.4457 * M_PI * 0.9693)};
     a.stamps = dS; a.variant = variant;
     a.waves_per_cu = argc > 5 ? atoi(argv[5]) : 0;
     a.single = 0;
+    a.counter = dC; a.fused = fused; a.xcd_chunk = xcd ? (int)((W + 7) / 8) : 0; a.nt_stores = nts;
 
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -107,5 +113,63 @@ int main(int argc, char **argv)
         const double m = med(d[i]);
         printf("  %-34s %9.0f cycles  %5.1f %%\n", names[i], m, 100.0 * m / tot);
     }
+    // timeline of the last launch from the s_memrealtime stamps (100 MHz): how long the machine takes to fill,
+    // how long it stays full, how long the tail is
+    std::vector<std::pair<unsigned long long, int>> ev;
+    unsigned long long t0 = ~0ull, t1 = 0;
+    std::vector<double> life;
+    for (long id = 0; id < blocks; id++) {
+        const unsigned long long *q = &S[(size_t)id * 10];
+        if (!q[7] || !q[8] || q[8] < q[7]) continue;
+        ev.push_back({q[7], +1}); ev.push_back({q[8], -1});
+        t0 = std::min(t0, q[7]); t1 = std::max(t1, q[8]);
+        life.push_back((double)(q[8] - q[7]) * 0.01);
+    }
+    std::sort(ev.begin(), ev.end());
+    int cur = 0, peak = 0;
+    for (auto &e : ev) { cur += e.second; peak = std::max(peak, cur); }
+    unsigned long long first_full = 0, last_full = 0;
+    cur = 0;
+    for (auto &e : ev) {
+        cur += e.second;
+        if (cur >= 0.9 * peak) { if (!first_full) first_full = e.first; last_full = e.first; }
+    }
+    double area = 0; cur = 0; unsigned long long prev = t0;
+    for (auto &e : ev) { area += (double)cur * (double)(e.first - prev); prev = e.first; cur += e.second; }
+    {   // concurrency over time (20 samples) and per-XCD shares; slot-idle time per CU from the HW ids
+        const int NS = 20;
+        std::vector<int> conc(NS, 0);
+        std::vector<std::vector<int>> cx(8, std::vector<int>(NS, 0));
+        std::map<unsigned, std::vector<std::pair<unsigned long long, unsigned long long>>> percu;
+        for (long id = 0; id < blocks; id++) {
+            const unsigned long long *q = &S[(size_t)id * 10];
+            if (!q[7] || !q[8] || q[8] < q[7]) continue;
+            const unsigned hw = (unsigned)(q[9] & 0xffffffffu), xcc = (unsigned)(q[9] >> 32) & 0xf;
+            const unsigned cu = (xcc << 16) | (hw & 0xff00);        // xcc | se, sh, cu
+            percu[cu].push_back({q[7], q[8]});
+            for (int k = 0; k < NS; k++) {
+                const unsigned long long t = t0 + (t1 - t0) * (2 * k + 1) / (2 * NS);
+                if (q[7] <= t && t < q[8]) { conc[k]++; cx[xcc & 7][k]++; }
+            }
+        }
+        printf("resident tile waves at 20 evenly spaced moments:");
+        for (int k = 0; k < NS; k++) printf(" %d", conc[k]);
+        printf("\n  of which on XCC 0 / 3 / 7:");
+        for (int k = 0; k < NS; k += 3) printf(" %d/%d/%d", cx[0][k], cx[3][k], cx[7][k]);
+        // per CU: mean resident waves and the idle time between one wave's end and the next start in steady state
+        double sum_res = 0; int ncu = 0; std::vector<double> gaps;
+        for (auto &kv : percu) {
+            auto &v = kv.second;
+            double busy = 0;
+            for (auto &w : v) busy += (double)(w.second - w.first);
+            sum_res += busy / (double)(t1 - t0); ncu++;
+        }
+        printf("\n  distinct CUs seen %d, mean resident waves per CU %.2f\n", ncu, ncu ? sum_res / ncu : 0.0);
+    }
+    printf("timeline (last launch): span first wave start -> last wave end %.2f us; peak %d resident tile waves (%.1f per CU); "
+           "fill to 90%% of peak %.2f us; at >= 90%% for %.2f us; tail after the last 90%% moment %.2f us; mean occupancy %.0f waves = %.0f %% of peak; "
+           "median wave life %.2f us\n",
+           (t1 - t0) * 0.01, peak, peak / 256.0, (first_full - t0) * 0.01, (last_full - first_full) * 0.01, (t1 - last_full) * 0.01,
+           area / (double)(t1 - t0), 100.0 * area / (double)(t1 - t0) / peak, med(life));
     return 0;
 }
