@@ -163,6 +163,8 @@ def callback_mode(tol_amd, mission, aircraft, ts, calls, cfg=None):
     x = np.ascontiguousarray(p.x0())
     us_native, F, G = p.time_callback(x, calls)
     assert np.isfinite(F).all() and np.isfinite(G).all() and F[0] != 0.0
+    us_f_only, F2, _ = p.time_callback(x, calls, needG=False)      # what snOptA's line search asks for
+    assert np.array_equal(F2, F)
     p.make_current()
     L = tol_amd.lib()
     dp = C.POINTER(C.c_double)
@@ -182,6 +184,7 @@ def callback_mode(tol_amd, mission, aircraft, ts, calls, cfg=None):
     rec = {"workload": f"{mission}/{aircraft}/ts={ts} single trajectory, DEFINEGusrfg_ host->host (PCIe inclusive)",
            "mode": "callback", "us_per_call": us_native, "node_evals_per_s": 1e6 * ts / us_native, "calls": calls,
            "entered_from": "native code through an snFunA pointer (tolfg_time_callback)",
+           "us_per_call_needF_only": us_f_only,
            "us_per_call_via_python_ctypes": 1e6 * dt / calls}
     if cfg is not None:
         rec["config"] = cfg

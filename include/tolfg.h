@@ -153,9 +153,11 @@ void DEFINEGusrfg_(int *Status, int *n, double x[],
 
 /* Measurement aid: enter DEFINEGusrfg_ `calls` times from native code through an snFunA function pointer,
  * the way snOptA does (x, F, G: caller arrays of the problem's sizes, the same ones every call), after
- * `warm` untimed calls; *us_per_call receives the mean wall time of one call.  Returns the last *Status
- * the callback left (1 = untouched) or a negative TOLFG_ERR_*. */
-int tolfg_time_callback(tolfg_problem *p, const double *x, double *F, double *G, int warm, int calls, double *us_per_call);
+ * `warm` untimed calls; *us_per_call receives the mean wall time of one call.  needF / needG are passed through
+ * (snOptA asks for F alone during its line searches).  Returns the last *Status the callback left (1 = untouched)
+ * or a negative TOLFG_ERR_*. */
+int tolfg_time_callback(tolfg_problem *p, const double *x, double *F, double *G, int needF, int needG, int warm, int calls,
+                        double *us_per_call);
 
 /* The three public methods DEFINEGusrfg_ dispatches to in the reference
  * (ref: problem::modelWind / computeF / computeG, src/problem.cpp:475,765,782), for callers that

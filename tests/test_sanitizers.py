@@ -53,6 +53,12 @@ int main(int argc, char **argv) {
                 }
         }
     }
+    {   // launch plan (plan.cpp): outputs that fit the Infinity Cache vs outputs beyond it
+        const LaunchPlan small = plan_launch(100e6, 0, PATTERN_REFERENCE), big = plan_launch(800e6, 0, PATTERN_REFERENCE);
+        const LaunchPlan big32 = plan_launch(800e6, 1, PATTERN_REFERENCE), bigc = plan_launch(800e6, 0, PATTERN_COMPACT);
+        if (small.nt_stores || small.waves_per_cu || !small.fused || !small.xcd || small.max_nt != 64) rc = 4;
+        if (!big.nt_stores || big.waves_per_cu != 8 || !big.fused || big32.waves_per_cu != 12 || bigc.fused) rc = 5;
+    }
     try { aircraft bad("no_such_airframe", root); rc = 3; } catch (const std::length_error &) {}
     std::printf("host sanitize run rc=%d\n", rc);
     return rc;

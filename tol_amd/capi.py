@@ -81,7 +81,7 @@ SYMBOLS = {
     "tolfg_get_current": (C.c_void_p, []),
     "tolfg_handle_index": (C.c_int, [C.c_void_p]),
     "DEFINEGusrfg_": (None, [_ip, _ip, _dp, _ip, _ip, _dp, _ip, _ip, _dp, C.c_char_p, _ip, _ip, _ip, _dp, _ip]),
-    "tolfg_time_callback": (C.c_int, [C.c_void_p, _dp, _dp, _dp, C.c_int, C.c_int, _dp]),
+    "tolfg_time_callback": (C.c_int, [C.c_void_p, _dp, _dp, _dp, C.c_int, C.c_int, C.c_int, C.c_int, _dp]),
     "tolfg_modelWind": (C.c_int, [C.c_void_p, _dp]),
     "tolfg_computeF": (C.c_int, [C.c_void_p, _dp, _dp]),
     "tolfg_computeG": (C.c_int, [C.c_void_p, _dp, _dp]),

@@ -222,7 +222,8 @@ void DEFINEGusrfg_(int *Status, int *n, double x[], int *needF, int *neF, double
     }
 }
 
-int tolfg_time_callback(tolfg_problem *h, const double *x, double *F, double *G, int warm, int calls, double *us_per_call)
+int tolfg_time_callback(tolfg_problem *h, const double *x, double *F, double *G, int needF, int needG, int warm, int calls,
+                        double *us_per_call)
 {
     if (!h || !x || !F || !G || calls < 1 || !us_per_call) return fail(TOLFG_ERR_ARG, "tolfg_time_callback: bad argument");
     typedef void (*snFunA)(int *, int *, double *, int *, int *, double *, int *, int *, double *, char *, int *, int *, int *,
@@ -230,11 +231,12 @@ int tolfg_time_callback(tolfg_problem *h, const double *x, double *F, double *G,
     volatile snFunA usrfun = DEFINEGusrfg_;
     tolfg_problem *keep = g_current;
     tolfg_set_current(h);
-    int Status = 1, n = h->p->n, neF = h->p->neF, neG = h->p->neG, one = 1, zero = 0;
+    int Status = 1, n = h->p->n, neF = h->p->neF, neG = h->p->neG, zero = 0;
+    int wantF = needF ? 1 : 0, wantG = needG ? 1 : 0;
     std::vector<double> xs(x, x + n);
-    for (int i = 0; i < warm; ++i) usrfun(&Status, &n, xs.data(), &one, &neF, F, &one, &neG, G, nullptr, &zero, nullptr, &zero, nullptr, &zero);
+    for (int i = 0; i < warm; ++i) usrfun(&Status, &n, xs.data(), &wantF, &neF, F, &wantG, &neG, G, nullptr, &zero, nullptr, &zero, nullptr, &zero);
     const auto t0 = std::chrono::steady_clock::now();
-    for (int i = 0; i < calls; ++i) usrfun(&Status, &n, xs.data(), &one, &neF, F, &one, &neG, G, nullptr, &zero, nullptr, &zero, nullptr, &zero);
+    for (int i = 0; i < calls; ++i) usrfun(&Status, &n, xs.data(), &wantF, &neF, F, &wantG, &neG, G, nullptr, &zero, nullptr, &zero, nullptr, &zero);
     const auto t1 = std::chrono::steady_clock::now();
     *us_per_call = std::chrono::duration<double, std::micro>(t1 - t0).count() / calls;
     tolfg_set_current(keep);

@@ -145,13 +145,13 @@ class Problem:
                                 C.byref(neG), _d(G), None, C.byref(zero), None, C.byref(zero), None, C.byref(zero))
         return F, G, st.value
 
-    def time_callback(self, x, calls, warm=50):
+    def time_callback(self, x, calls, warm=50, needF=True, needG=True):
         """Mean wall time (us) of one DEFINEGusrfg_ call entered from native code like snOptA enters it; F and G
         are the same arrays every call.  Returns (us_per_call, F, G)."""
         x = np.ascontiguousarray(x, dtype=np.float64)
         F, G = np.zeros(self.neF), np.zeros(self.neG)
         us = C.c_double()
-        st = lib().tolfg_time_callback(self._h, _d(x), _d(F), _d(G), int(warm), int(calls), C.byref(us))
+        st = lib().tolfg_time_callback(self._h, _d(x), _d(F), _d(G), int(needF), int(needG), int(warm), int(calls), C.byref(us))
         if st != 1:
             check(st if st < 0 else capi.ERR_HIP)
         return us.value, F, G

@@ -10,8 +10,8 @@ print("value %.4g %s on %d GPU(s), %s scaling, backend %s; ms/step %.4f; evaluat
       % (d["value"], d["unit"], d["n_gpus"], d["scaling"], d.get("backend"), d["ms_per_step"], r["kernel_ms"], r["kernel_min_ms"], r["achieved"], r["frac"]))
 for c in d.get("configs", []):
     if c["mode"] == "callback":
-        print("  config %d callback: %.1f us/call native (%.1f via ctypes) = %.3g node-evals/s  [%s]"
-              % (c["config"], c["us_per_call"], c["us_per_call_via_python_ctypes"], c["node_evals_per_s"], c["workload"]))
+        print("  config %d callback: %.1f us/call native (%.1f via ctypes; F only %.1f) = %.3g node-evals/s  [%s]"
+              % (c["config"], c["us_per_call"], c["us_per_call_via_python_ctypes"], c.get("us_per_call_needF_only", float("nan")), c["node_evals_per_s"], c["workload"]))
     else:
         print("  config %d B=%d %s: step %.1f us, evaluation %.1f us (min %.1f) = %.0f GB/s = %.3f of peak, %.3g node-evals/s  [%s]"
               % (c["config"], c["batch"], c["dtype"], 1e3 * c["ms_per_step"], c["eval_us"], c["eval_min_us"], c["achieved_GBs"], c["frac_of_hbm_peak"],
