@@ -23,3 +23,7 @@ if "cpu_baseline" in d:
 if "next_compact_pattern" in d:
     c = d["next_compact_pattern"]
     print("  compact pattern: %.4g node-evals/s, evaluation %.4f ms = %.3f of peak" % (c["value"], c["kernel_ms"], c["frac_of_hbm_peak"]))
+if "two_batches_two_streams" in d:
+    c = d["two_batches_two_streams"]
+    print("  two batches on two streams: %.1f us per evaluation, %.4g node-evals/s = %.3f of peak (whole wall time)"
+          % (c["us_per_evaluation"], c["node_evals_per_s"], c["frac_of_hbm_peak"]))
