@@ -314,3 +314,37 @@ def test_slab_stream_at_every_alignment(tolfg, oracle, mission, N, dtype):
                 assert_close(Gt, ref[t][1], mask=ops[t].undefined_mask(), what=f"G[{t}] offset {k}")
             else:
                 assert_close_f32(Ft, Gt, ref[t][0], ref[t][1], iG, N, mask=ops[t].undefined_mask(), what=f"f32 [{t}] offset {k}")
+
+
+@pytest.mark.parametrize("fused", ["1", "0"])
+@pytest.mark.parametrize("mission,tail", [("S10", "7:16"), ("mixed", "20:32"), ("G7", "33:8")])
+def test_finer_tiled_tail_gives_the_same_results(tolfg, oracle, monkeypatch, mission, tail, fused):
+    """TOLFG_TAIL=count:nt (a measurement knob, off by default: profiles/r02_tail_tiles.md) cuts the last `count`
+    trajectories of a launch into finer tiles.  Defects and the Jacobian must be bitwise what the plain tiling
+    gives; the objective is summed over different tile partials, so 1e-13."""
+    import torch
+    N, B = 200, 33
+    def run(env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        bt = tolfg.Batch(mission, AIRCRAFT, ts=N)
+        ms = [("S10", "G7")[t % 2] if mission == "mixed" else mission for t in range(B)]
+        bt.set_trajectories([tolfg.Trajectory(aircraft=t % 5, mission=ms[t], radius_goal=100.0 if ms[t] == "S10" else 0.0,
+                                              Vref=1.0 + 0.1 * t) for t in range(B)])
+        dX, dF, dG = bt.alloc(B)
+        bt.x0_device(dX)
+        dX[:, 1:bt.n] += 0.01 * torch.randn(B, bt.n - 1, dtype=torch.float64, device="cuda", generator=torch.Generator("cuda").manual_seed(11))
+        dF.zero_(); dG.zero_()
+        for _ in range(2):                                   # twice: the arrival counters must be left at zero
+            bt.eval(dX, dF, dG)
+        torch.cuda.synchronize()
+        out = dF.cpu().numpy().copy(), dG.cpu().numpy().copy()
+        bt.close()
+        for k in env:
+            monkeypatch.delenv(k)
+        return out
+    F0, G0 = run({"TOLFG_FUSED": fused})
+    F1, G1 = run({"TOLFG_FUSED": fused, "TOLFG_TAIL": tail})
+    assert np.array_equal(G0, G1, equal_nan=True)
+    assert np.array_equal(F0[:, 1:], F1[:, 1:], equal_nan=True)
+    assert_close(F1[:, 0], F0[:, 0], tol=1e-13, what="objective with a finer-tiled tail")

@@ -61,6 +61,11 @@ struct FgArgs {
     int  B, N;
     int  c0[2];            // position in G of node 0's slab, per mission
     int  tiles, nt;        // tiles per trajectory and nodes per tile, from plan_tiles()
+    // Finer tiles for the trajectories the launch reaches last: the last tail_count trajectories (0 = none)
+    // are cut into tail_tiles tiles of tail_nt <= nt nodes; their workgroup ids follow those of the body, so the
+    // waves the machine runs while it drains are short-lived.  Tile numbering, with tb = B - tail_count: body
+    // tile t of trajectory b < tb is b * tiles + t; tail tile t of b >= tb is tb * tiles + (b - tb) * tail_tiles + t.
+    int  tail_count, tail_tiles, tail_nt;
     int  needF, needG;
     int  pattern;          // PATTERN_REFERENCE (104-entry slabs) | PATTERN_COMPACT (46-entry slabs)
     int  waves_per_cu;     // cap on resident tile waves per CU (0 = whatever fits); host-side launch hint
@@ -104,6 +109,7 @@ struct LaunchPlan {
     int nt_stores;         // non-temporal slab stream
     int xcd;               // deal the tiles to the XCDs in contiguous eighths
     int fused;             // the last-arriving tile wave finalizes (one launch) vs finalize_kernel as a second launch
+    int tail_count, tail_nt;   // the last tail_count trajectories in tiles of <= tail_nt nodes (0 = no tail)
 };
 LaunchPlan plan_launch(double out_bytes, int dtype, int pattern);
 

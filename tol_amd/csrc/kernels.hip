@@ -476,6 +476,29 @@ struct Publish {
 // wave's own TILE*RS-element region; sumT / sumP return the tile's objective terms (wave-uniform).
 struct NoHook { __device__ __forceinline__ void operator()() const {} };
 
+// Where a tile lies: trajectory, first node, tiling of that trajectory, number of the trajectory's first tile.
+struct TileAt { int b, k0, tiles, nt, first; };
+
+__device__ __forceinline__ long body_tiles(const FgArgs &a) { return (long)(a.B - a.tail_count) * a.tiles; }
+__device__ __forceinline__ long total_tiles(const FgArgs &a) { return body_tiles(a) + (long)a.tail_count * a.tail_tiles; }
+
+__device__ __forceinline__ TileAt tile_at(const FgArgs &a, int item)
+{
+    const int tb = a.B - a.tail_count, body = tb * a.tiles;
+    if (item < body) {                                       // wave-uniform
+        const int b = item / a.tiles;
+        return {b, (item - b * a.tiles) * a.nt, a.tiles, a.nt, b * a.tiles};
+    }
+    const int r = item - body, q = r / a.tail_tiles;
+    return {tb + q, (r - q * a.tail_tiles) * a.tail_nt, a.tail_tiles, a.tail_nt, body + q * a.tail_tiles};
+}
+
+__device__ __forceinline__ long first_tile_of(const FgArgs &a, int b)
+{
+    const int tb = a.B - a.tail_count;
+    return b < tb ? (long)b * a.tiles : body_tiles(a) + (long)(b - tb) * a.tail_tiles;
+}
+
 // `after_window` runs once the x window has been consumed (the wave's loads are back): the persistent form
 // asks for its next tile there, so that the atomic's round trip hides behind the arithmetic and the stores
 // instead of sitting in front of the window loads (vmcnt counts in order).
@@ -490,9 +513,9 @@ __device__ __forceinline__ void tile_body(const FgArgs &a, T *lds, int item, int
     constexpr int SLABN = SlabGeom<PAT, GV>::SLABN;
     constexpr int NW = ((NI * TILE + 9 + VEC - 1) / VEC + TILE - 1) / TILE;   // window vectors per lane
     const int N = a.N;
-    const int b = item / a.tiles;
-    const int k0 = (item - b * a.tiles) * a.nt;
-    const int cnt = min(a.nt, N - k0);
+    const TileAt at = tile_at(a, item);
+    const int b = at.b, k0 = at.k0;
+    const int cnt = min(at.nt, N - k0);
     const T *xrow = static_cast<const T *>(a.X) + (long)b * a.ldx;
     T *Frow = static_cast<T *>(a.F) + (long)b * a.ldf;
     T *Grow = static_cast<T *>(a.G) + (long)b * a.ldg;
@@ -803,7 +826,8 @@ __device__ __forceinline__ void sum_partials(const double *part, int tiles, int 
 template <typename T, int MISSION, int WIND, int VEC, int PAT, bool NT, typename Hook = NoHook>
 __device__ __forceinline__ void run_tile(const FgArgs &a, T *lds, int item, int lane, Hook after_window = Hook())
 {
-    const int b = item / a.tiles;
+    const TileAt at = tile_at(a, item);
+    const int b = at.b;
     T sumT, sumP;
     Publish pub{nullptr, nullptr, 0u};
     if (a.fused) {
@@ -813,10 +837,10 @@ __device__ __forceinline__ void run_tile(const FgArgs &a, T *lds, int item, int 
     tile_body<T, MISSION, WIND, VEC, PAT, NT>(a, lds, item, lane, sumT, sumP, pub, after_window);
     if (a.fused) {
         const unsigned old = __builtin_amdgcn_readfirstlane(pub.old);
-        if (old == (unsigned)(a.tiles - 1)) {          // wave-uniform: every tile of b has arrived
+        if (old == (unsigned)(at.tiles - 1)) {         // wave-uniform: every tile of b has arrived
             if (lane == 0) __hip_atomic_store(pub.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             T st = T(0), sp = T(0);
-            if (a.needF) sum_partials<T, true>(a.partial + 2 * (long)b * a.tiles, a.tiles, lane, st, sp);
+            if (a.needF) sum_partials<T, true>(a.partial + 2 * (long)at.first, at.tiles, lane, st, sp);
             finalize_body<T, MISSION, PAT>(a, b, lane, st, sp);
         }
     } else if (a.needF && lane == 0) {
@@ -893,9 +917,9 @@ __global__ __launch_bounds__(TILE, TOLFG_MIN_WAVES_PER_SIMD) void fg_kernel(cons
     {
         int item = blockIdx.x;
         if (item < 8 * a.xcd_chunk) item = (item & 7) * a.xcd_chunk + (item >> 3);     // the rest (the launch's tail) in id order
-        if (item >= a.B * a.tiles) return;             // the grid may be rounded up to 8 * xcd_chunk
+        if (item >= total_tiles(a)) return;            // the grid may be rounded up to 8 * xcd_chunk
         run_tile<T, MISSION, WIND, VEC, PAT, NT>(a, lds, item, lane);
-        if (a.done) signal_done(a, a.B * a.tiles, lane == 0);
+        if (a.done) signal_done(a, (int)total_tiles(a), lane == 0);
         return;
     }
 #ifdef TOLFG_PERSIST_EXPERIMENT
@@ -930,7 +954,7 @@ __global__ __launch_bounds__(TILE) void finalize_kernel(const FgArgs a)
 {
     const int b = blockIdx.x;
     T sumT = T(0), sumP = T(0);
-    if (a.needF) sum_partials<T, false>(a.partial + 2 * (long)b * a.tiles, a.tiles, threadIdx.x, sumT, sumP);
+    if (a.needF) sum_partials<T, false>(a.partial + 2 * first_tile_of(a, b), b < a.B - a.tail_count ? a.tiles : a.tail_tiles, threadIdx.x, sumT, sumP);
     finalize_body<T, MISSION, PAT>(a, b, threadIdx.x, sumT, sumP);
 }
 
@@ -1208,7 +1232,11 @@ hipError_t launch_fg(const FgArgs &a, int mission, int wind, int dtype, int vec,
         return hipErrorInvalidValue;
     if ((a.fused || a.done) && !a.counter) return hipErrorInvalidValue;
     if (a.done && !a.fused && !a.single) return hipErrorInvalidValue;     // finalize_kernel would still be running
-    const long W = (long)a.B * a.tiles;
+    if (a.tail_count < 0 || a.tail_count > a.B) return hipErrorInvalidValue;
+    if (a.tail_count > 0 && (a.single || a.persist || a.tail_nt < 4 || a.tail_nt > a.nt || (a.tail_nt & 3) ||
+                              a.tail_tiles != (a.N + a.tail_nt - 1) / a.tail_nt))
+        return hipErrorInvalidValue;
+    const long W = (long)(a.B - a.tail_count) * a.tiles + (long)a.tail_count * a.tail_tiles;
     if (W > 0x7ffffff0L) return hipErrorInvalidValue;
     if (a.xcd_chunk < 0 || a.xcd_chunk > (int)((W + 7) / 8)) return hipErrorInvalidValue;
 #ifdef TOLFG_PERSIST_EXPERIMENT

@@ -112,6 +112,10 @@ batch::batch(const std::string &mission, const std::string &root, const std::vec
     if (const char *e = std::getenv("TOLFG_FUSED")) fused_forced_ = std::atoi(e) != 0;
     if (const char *e = std::getenv("TOLFG_NT_STORES")) nt_forced_ = std::atoi(e) != 0;
     if (const char *e = std::getenv("TOLFG_XCD")) xcd_forced_ = std::atoi(e) != 0;
+    if (const char *e = std::getenv("TOLFG_TAIL")) {        // "count:nt", count 0 = no tail
+        tail_forced_ = std::atoi(e);
+        if (const char *c = std::strchr(e, ':')) tail_nt_forced_ = std::atoi(c + 1);
+    }
     for (int m = 0; m < 2; ++m) {
         const gain &g = gains(m);
         args_.c0[m] = szm_[m].c0;
@@ -265,7 +269,16 @@ void batch::eval(int B, const void *dX, long ldx, void *dF, long ldf, void *dG, 
     const double out_bytes = (double)elem_size() * B * ((needF ? sz_.neF : 0) + (needG ? sz_.neG : 0));
     const LaunchPlan lp = plan_launch(out_bytes, dtype_, a.pattern);
     plan_tiles(a.N, dtype_, a.single ? 0 : (tile_nodes_forced_ > 0 ? tile_nodes_forced_ : lp.max_nt), &a.tiles, &a.nt);
-    const long W = (long)B * a.tiles;
+    // finer tiles for the trajectories the launch reaches last (FgArgs::tail_count)
+    a.tail_count = a.tail_tiles = a.tail_nt = 0;
+    const int tail_count = a.single ? 0 : std::min(B, tail_forced_ >= 0 ? tail_forced_ : lp.tail_count);
+    if (tail_count > 0) {
+        const int tnt = tail_nt_forced_ > 0 ? tail_nt_forced_ : lp.tail_nt;
+        a.tail_count = tail_count;
+        plan_tiles(a.N, dtype_, std::min(tnt, a.nt), &a.tail_tiles, &a.tail_nt);
+    }
+    const long body = (long)(B - a.tail_count) * a.tiles;
+    const long W = body + (long)a.tail_count * a.tail_tiles;
     if (W > partial_cap_) {        // objective partials, 2 doubles per tile
         check(hipSetDevice(device_), "hipSetDevice");
         if (d_partial_) check(hipFree(d_partial_), "hipFree");
@@ -290,7 +303,7 @@ void batch::eval(int B, const void *dX, long ldx, void *dF, long ldf, void *dG, 
     a.done = done; a.done_seq = done_seq;
     a.waves_per_cu = waves_forced_ ? waves_per_cu_ : lp.waves_per_cu;
     a.nt_stores = nt_forced_ >= 0 ? nt_forced_ : lp.nt_stores;
-    a.xcd_chunk = ((xcd_forced_ >= 0 ? xcd_forced_ : lp.xcd) && !a.single) ? (int)((W + 7) / 8) : 0;
+    a.xcd_chunk = ((xcd_forced_ >= 0 ? xcd_forced_ : lp.xcd) && !a.single) ? (int)(a.tail_count ? body / 8 : (W + 7) / 8) : 0;
     a.X = dX; a.ldx = ldx; a.F = dF; a.ldf = ldf; a.G = dG; a.ldg = ldg;
     a.wind = dWind; a.traj = d_traj_;
     a.B = B; a.needF = needF ? 1 : 0; a.needG = needG ? 1 : 0;

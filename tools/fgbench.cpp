@@ -54,7 +54,7 @@ struct Buffers {
     double *dP = nullptr;
     unsigned *dC = nullptr, *dQ = nullptr;
     long capW = 0, poll_ready = -1;
-    int nt = 1, xcd = 0, pat = 0, persist = 0, xcdpct = 100;
+    int nt = 1, xcd = 0, pat = 0, persist = 0, xcdpct = 100, tail_count = 0, tail_nt = 16;
     size_t es() const { return sh.dtype == 0 ? 8 : 4; }
     void release()
     {
@@ -123,14 +123,19 @@ tolfg::FgArgs make_args(Buffers &bf, int max_nt, int cap, int fused, int xi, voi
     a.X = bf.dX[xi % bf.dX.size()]; a.ldx = sh.ldx; a.F = F; a.ldf = sh.ldf; a.G = G; a.ldg = sh.ldg;
     a.wind = nullptr; a.traj = bf.dT; a.B = sh.B; a.N = sh.N; a.c0[0] = 3 * sh.N + 4; a.c0[1] = sh.N + 6;
     tolfg::plan_tiles(sh.N, sh.dtype, max_nt, &a.tiles, &a.nt);
-    const long W = (long)sh.B * a.tiles;
+    if (bf.tail_count > 0 && !bf.persist) {                 // finer tiles for the trajectories reached last
+        a.tail_count = bf.tail_count < sh.B ? bf.tail_count : sh.B;
+        tolfg::plan_tiles(sh.N, sh.dtype, bf.tail_nt < a.nt ? bf.tail_nt : a.nt, &a.tail_tiles, &a.tail_nt);
+    }
+    const long body = (long)(sh.B - a.tail_count) * a.tiles;
+    const long W = body + (long)a.tail_count * a.tail_tiles;
     if (W > bf.capW) {
         if (bf.dP) CK(hipFree(bf.dP));
         CK(hipMalloc(&bf.dP, sizeof(double) * 2 * W));
         bf.capW = W;
     }
     a.partial = bf.dP; a.counter = bf.dC; a.queues = bf.dQ; a.fused = fused; a.single = 0; a.obj = nullptr;
-    a.nt_stores = bf.nt; a.xcd_chunk = (bf.xcd || bf.persist) ? (int)((bf.persist ? W + 7 : W * bf.xcdpct / 100) / 8) : 0;
+    a.nt_stores = bf.nt; a.xcd_chunk = (bf.xcd || bf.persist) ? (int)((bf.persist ? W + 7 : (a.tail_count ? body : W) * bf.xcdpct / 100) / 8) : 0;
     a.persist = (bf.persist > 0 && W > 256L * bf.persist) ? 1 : 0; a.persist_groups = 256 * bf.persist;
     if (fused && bf.poll_ready != W) {   // slots start empty; the unfused path leaves values behind
         CK(hipMemsetD32(reinterpret_cast<hipDeviceptr_t>(bf.dP), tolfg::kEmptySlotWord, 4 * (size_t)W));
@@ -186,6 +191,7 @@ int main(int argc, char **argv)
         if (!strncmp(argv[i], "nt=", 3)) { bf.nt = atoi(argv[i] + 3); continue; }
         if (!strncmp(argv[i], "xcd=", 4)) { bf.xcd = atoi(argv[i] + 4); continue; }
         if (!strncmp(argv[i], "xcdpct=", 7)) { bf.xcdpct = atoi(argv[i] + 7); continue; }       // share of the tiles dealt XCD-contiguously
+        if (!strncmp(argv[i], "tail=", 5)) { bf.tail_count = atoi(argv[i] + 5); const char *c = strchr(argv[i], ':'); if (c) bf.tail_nt = atoi(c + 1); continue; }   // tail=count:nt
         if (!strncmp(argv[i], "persist=", 8)) { bf.persist = atoi(argv[i] + 8); continue; }     // workgroups per CU, 0 = off
         if (!strncmp(argv[i], "pat=", 4)) { bf.pat = atoi(argv[i] + 4); bf.release(); bf.sh = Shape{}; continue; }
         int v[7] = {4096, 200, 64, 0, 0, 0, 0};
@@ -196,9 +202,10 @@ int main(int argc, char **argv)
             // keep the X buffers together above the Infinity Cache only when the shape is large anyway
             fill(bf, sh, xbuf);
             const int nt_keep = bf.nt, xcd_keep = bf.xcd;
+            const int tail_keep = bf.tail_count; bf.tail_count = 0;
             bf.nt = 1; bf.xcd = 0;
             tolfg::FgArgs r = make_args(bf, 64, 0, 0, 0, bf.dF2, bf.dG2);     // reference result of this shape
-            bf.nt = nt_keep; bf.xcd = xcd_keep;
+            bf.nt = nt_keep; bf.xcd = xcd_keep; bf.tail_count = tail_keep;
             CK(tolfg::launch_fg(r, sh.mission, tolfg::WIND_SHEAR, sh.dtype, sh.dtype == 0 ? 2 : 4, st));
             CK(hipStreamSynchronize(st));
         }
@@ -236,9 +243,11 @@ int main(int argc, char **argv)
         const long neG_eff = bf.pat == tolfg::PATTERN_COMPACT ? sh.c0 + 46L * sh.N + (sh.mission == tolfg::MISSION_G7 ? 30 : 22) : sh.neG;
         const double bytes = (double)bf.es() * sh.B * ((double)sh.n + sh.neF + neG_eff);
         const double us = 1e3 * ms / reps;
-        printf("| %d | %d | %s | %s | %d -> %d x %d | %d | %d%s%s | %.2f | %.2f | %.0f | %.1f | %s |\n", sh.B, sh.N,
+        char tailtxt[48] = "";
+        if (a.tail_count) snprintf(tailtxt, sizeof tailtxt, " tail %d x (%d x %d)", a.tail_count, a.tail_tiles, a.tail_nt);
+        printf("| %d | %d | %s | %s | %d -> %d x %d | %d | %d%s%s%s | %.2f | %.2f | %.0f | %.1f | %s |\n", sh.B, sh.N,
                sh.mission == 0 ? "S10" : (sh.mission == 1 ? "G7" : "mixed"), sh.dtype == 0 ? "f64" : "f32", v[2], a.tiles, a.nt, v[3], v[4],
-               bf.nt ? " nt" : " plain", a.persist ? " persist" : (bf.xcd ? (bf.xcdpct == 100 ? " xcd" : " xcd-part") : ""), us, kern_us,
+               bf.nt ? " nt" : " plain", a.persist ? " persist" : (bf.xcd ? (bf.xcdpct == 100 ? " xcd" : " xcd-part") : ""), tailtxt, us, kern_us,
                bytes / (1e3 * us), 100.0 * bytes / (1e3 * us) / 8000.0, (bad || bad2) ? "MISMATCH" : "ok");
         fflush(stdout);
     }

@@ -11,6 +11,9 @@
 //   mode 7: workgroups of GRP waves write one contiguous S KiB region together, KiB chunks interleaved over the waves
 //   mode 8: like 7 but wave w writes the w-th contiguous S/GRP KiB piece of the region
 //   mode 9: mode 4 after `delay` x 64 s_sleep(8) of idling (long-lived waves, short streams)
+//   mode 11: long-lived waves, interleaved globally: wave j of a super-group of G (= `delay`, 0 -> all) waves writes GRP-KiB
+//            chunks j, j+G, j+2G, ... of the super-group's G*S KiB region (compact in-flight address window, long streams)
+//   mode 13: mode 4 with the segments dealt in a scattered order (segment = id * 7919 mod nblocks)
 //   mode 10: mode 7 where every wave first reads 1 KiB and idles `delay` x 64 s_sleep(8) (load -> compute -> store)
 // LDS bytes per block (dynamic) limit the occupancy like the real kernel's 22 KB does.
 //
@@ -76,6 +79,19 @@ __global__ __launch_bounds__(64) void wr(vec2 *out, int S, int grp, int delay, l
         for (int d = 0; d < delay * 64; d++) __builtin_amdgcn_s_sleep(8);
         vec2 *base = out + id * S * 64;
         for (int i = 0; i < S; i++) __builtin_nontemporal_store(v, &base[(long)i * 64 + lane]);
+    } else if (MODE == 11) {
+        const long G = delay > 0 ? delay : nblocks, g = id / G, j = id % G;
+        const long Gn = min(G, nblocks - g * G);             // the last super-group may be short
+        const int C = grp, chunks = S / C;
+        vec2 *base = out + g * G * S * 64;
+        for (int i = 0; i < chunks; i++) {
+            vec2 *c = base + (j + Gn * i) * C * 64;
+            for (int q = 0; q < C; q++) __builtin_nontemporal_store(v, &c[(long)q * 64 + lane]);
+        }
+    } else if (MODE == 13) {
+        const long seg = (id * 7919L) % nblocks;
+        vec2 *base = out + seg * S * 64;
+        for (int i = 0; i < S; i++) __builtin_nontemporal_store(v, &base[(long)i * 64 + lane]);
     } else if (MODE == 5) {       // mode 1 (interleaved groups) with non-temporal stores
         const long g = id / grp, w = id % grp;
         vec2 *base = out + (g * grp * S) * 64;
@@ -114,6 +130,8 @@ int main(int argc, char **argv)
         if (mode == 9) hipLaunchKernelGGL(wr<9>, dim3(nblocks), dim3(64), lds, 0, d, S, grp, delay, nblocks);
         if (mode == 7) hipLaunchKernelGGL(wrg<7>, dim3(nblocks), dim3(64 * grp), lds, 0, d, S, grp, delay, nblocks);
         if (mode == 8) hipLaunchKernelGGL(wrg<8>, dim3(nblocks), dim3(64 * grp), lds, 0, d, S, grp, delay, nblocks);
+        if (mode == 11) hipLaunchKernelGGL(wr<11>, dim3(nblocks), dim3(64), lds, 0, d, S, grp, delay, nblocks);
+        if (mode == 13) hipLaunchKernelGGL(wr<13>, dim3(nblocks), dim3(64), lds, 0, d, S, grp, delay, nblocks);
         if (mode == 10) hipLaunchKernelGGL(wrg<10>, dim3(nblocks), dim3(64 * grp), lds, 0, d, S, grp, delay, nblocks);
     };
     for (int i = 0; i < 3; i++) launch();
