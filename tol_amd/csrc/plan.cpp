@@ -40,8 +40,9 @@ LaunchPlan plan_launch(double out_bytes, int dtype, int pattern)
     const bool beyond_cache = out_bytes > 192.0 * 1024 * 1024;
     p.max_nt = kTileNodes;
     p.nt_stores = beyond_cache ? 1 : 0;
-    p.waves_per_cu = beyond_cache ? (dtype == 0 ? 8 : 12) : 0;
-    (void)pattern;
+    // fp32 compact slabs (184 bytes per node) are the one shape that wants every wave it can get beyond the cache
+    // too: cap 12 / none -> 55.1 / 50.7 us at B=4096, 112.0 / 106.0 us for the mixed 8192 (tools/exp_r02ab.sh)
+    p.waves_per_cu = beyond_cache ? (dtype == 0 ? 8 : (pattern == PATTERN_COMPACT ? 0 : 12)) : 0;
     p.xcd = 1;
     // one launch per evaluation, except for the compact pattern beyond the cache, where the two-launch form
     // measured 5 % faster (103.3 vs 108.0 us at B=4096: half the bytes per node, so the finalizing waves' tails weigh more)

@@ -14,6 +14,9 @@
 //   mode 11: long-lived waves, interleaved globally: wave j of a super-group of G (= `delay`, 0 -> all) waves writes GRP-KiB
 //            chunks j, j+G, j+2G, ... of the super-group's G*S KiB region (compact in-flight address window, long streams)
 //   mode 13: mode 4 with the segments dealt in a scattered order (segment = id * 7919 mod nblocks)
+//   mode 14: mode 4 (S KiB per wave, in order) but every store instruction is spread over 64/GRP sub-regions of the wave's
+//            region: lanes [g*GRP, (g+1)*GRP) write GRP*16 contiguous bytes of sub-region g (one instruction touches
+//            64/GRP places S/(64/GRP) KiB apart instead of one contiguous KiB)
 //   mode 10: mode 7 where every wave first reads 1 KiB and idles `delay` x 64 s_sleep(8) (load -> compute -> store)
 // LDS bytes per block (dynamic) limit the occupancy like the real kernel's 22 KB does.
 //
@@ -88,6 +91,11 @@ __global__ __launch_bounds__(64) void wr(vec2 *out, int S, int grp, int delay, l
             vec2 *c = base + (j + Gn * i) * C * 64;
             for (int q = 0; q < C; q++) __builtin_nontemporal_store(v, &c[(long)q * 64 + lane]);
         }
+    } else if (MODE == 14) {
+        const int LG = grp, subs = 64 / LG;                  // S * 64 vec2 per region, S * 64 / subs per sub-region
+        const long sub_len = (long)S * 64 / subs;
+        vec2 *base = out + id * S * 64 + (lane / LG) * sub_len + lane % LG;
+        for (int i = 0; i < S; i++) __builtin_nontemporal_store(v, &base[(long)i * LG]);
     } else if (MODE == 13) {
         const long seg = (id * 7919L) % nblocks;
         vec2 *base = out + seg * S * 64;
@@ -131,6 +139,7 @@ int main(int argc, char **argv)
         if (mode == 7) hipLaunchKernelGGL(wrg<7>, dim3(nblocks), dim3(64 * grp), lds, 0, d, S, grp, delay, nblocks);
         if (mode == 8) hipLaunchKernelGGL(wrg<8>, dim3(nblocks), dim3(64 * grp), lds, 0, d, S, grp, delay, nblocks);
         if (mode == 11) hipLaunchKernelGGL(wr<11>, dim3(nblocks), dim3(64), lds, 0, d, S, grp, delay, nblocks);
+        if (mode == 14) hipLaunchKernelGGL(wr<14>, dim3(nblocks), dim3(64), lds, 0, d, S, grp, delay, nblocks);
         if (mode == 13) hipLaunchKernelGGL(wr<13>, dim3(nblocks), dim3(64), lds, 0, d, S, grp, delay, nblocks);
         if (mode == 10) hipLaunchKernelGGL(wrg<10>, dim3(nblocks), dim3(64 * grp), lds, 0, d, S, grp, delay, nblocks);
     };
