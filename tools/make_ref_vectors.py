@@ -20,7 +20,11 @@ The interpreter reads a scalar declared without an initialiser as NaN, so the re
 undefined S10 entries (src/problemS10.cpp:397) come out as NaN in G; the fixture keeps them as NaN and
 the tests mask them.
 
-usage: python tools/make_ref_vectors.py            (writes tests/golden/ref_eval_vectors.npz)
+usage: python tools/make_ref_vectors.py                   (writes tests/golden/ref_eval_vectors.npz, ~1 min)
+       python tools/make_ref_vectors.py --set shipped     (writes tests/golden/ref_eval_shipped.npz: the repository as
+                                                           shipped -- both missions x all five air frames at ts = 100, and
+                                                           ts = 200 once per mission -- countG included; ~9 min on 6 cores)
+       python tools/make_ref_vectors.py --set long        (writes tests/golden/ref_eval_long.npz: S10 / skywalker / ts = 2000)
 """
 import math
 import os
@@ -35,7 +39,9 @@ sys.path.insert(0, os.path.join(HERE, "refeval"))
 import cinterp  # noqa: E402
 
 REF = "/root/reference"
-OUT = os.path.join(os.path.dirname(HERE), "tests", "golden", "ref_eval_vectors.npz")
+OUT = os.environ.get("REF_VECTORS_OUT") or os.path.join(os.path.dirname(HERE), "tests", "golden", "ref_eval_vectors.npz")
+OUT_LONG = os.environ.get("REF_VECTORS_OUT") or os.path.join(os.path.dirname(HERE), "tests", "golden", "ref_eval_long.npz")
+OUT_SHIPPED = os.environ.get("REF_VECTORS_OUT") or os.path.join(os.path.dirname(HERE), "tests", "golden", "ref_eval_shipped.npz")
 
 
 def read_param_values(path):
@@ -60,7 +66,7 @@ def aircraft_members(v):
 class RefProblem:
     """The members a constructed problemS10 / problemG7 holds (src/problem.cpp:13-192), as data."""
 
-    def __init__(self, mission, N, ac, gains, lim, goal, start):
+    def __init__(self, mission, N, ac, gains, lim, goal, start, lenG=None):
         self._classes = ["problem" + mission, "problem"]
         nb = 11 if mission == "S10" else 12
         self.sn = NS(ts=int(N), numinp=11, numstates=8, numbounds=nb, opt_tol=1e-6, feas_tol=1e-6)
@@ -91,7 +97,8 @@ class RefProblem:
             setattr(self, name, [0.0] * T)                                      # :137-148
         self.n = 11 * (N + 1) + 1                                               # :151
         self.neF = 8 * N + 1 + nb                                               # :152
-        lenG = self.neF * self.n                                                # :159
+        if lenG is None:
+            lenG = self.neF * self.n                                            # :159 (352 million at ts = 2000: the "long" set passes neG)
         self.lenG = lenG
         self.iGfun, self.jGvar = [0] * lenG, [0] * lenG
         self.x, self.xlow, self.xupp = [0.0] * self.n, [0.0] * self.n, [0.0] * self.n
@@ -140,50 +147,52 @@ def perturbed(x0, N, rng, scale=0.05):
     return x
 
 
-def main():
+SRC_FILES = ("problem.cpp", "problemS10.cpp", "problemG7.cpp")
+WIND_NAMES = ("u", "v", "w", "du_dx", "du_dy", "du_dz", "dv_dx", "dv_dy", "dv_dz", "dw_dx", "dw_dy", "dw_dz")
+
+
+def run_case(job):
+    """One case, start to finish, in the reference's own calling order.  job: dict(tag, ci, mission, N, airframe, goal,
+    start, kind) with kind "small" (non-shipped gains, perturbed air frames, table / grid wind) or "shipped"
+    (everything as the repository ships it; wind models 1 and 0)."""
     t_start = time.time()
-    srcs = [open(os.path.join(REF, "src", f), errors="replace").read() for f in ("problem.cpp", "problemS10.cpp", "problemG7.cpp")]
-    it = cinterp.Interp(srcs)
+    it = cinterp.Interp([open(os.path.join(REF, "src", f), errors="replace").read() for f in SRC_FILES])
+    ci, mission, N, airframe, goal, start, kind = (job[k] for k in ("ci", "mission", "N", "airframe", "goal", "start", "kind"))
+    tag = job["tag"]
     out = {}
-    cases = []
-    airframes = ["tempest", "skywalker"]
-    spec = [  # (mission, N, airframe, goal (east, north, up, radius), start)
-        ("S10", 6, "tempest", (400.0, 0.0, 70.0, 100.0), (0.0, 0.0, 0.0)),
-        ("G7", 6, "tempest", (400.0, 0.0, 70.0, 0.0), (0.0, 0.0, 0.0)),
-        ("S10", 9, "skywalker", (250.0, -120.0, 70.0, 80.0), (15.0, -25.0, -40.0)),
-        ("G7", 9, "skywalker", (300.0, 200.0, 70.0, 0.0), (-20.0, 30.0, -55.0)),
-        # odd ts: c0 is odd, so the product takes its scalar-store kernels; 20 nodes: more than one 16-node store group
-        ("S10", 13, "tempest", (380.0, 40.0, 70.0, 120.0), (5.0, 8.0, -35.0)),
-        ("G7", 20, "tempest", (350.0, -150.0, 70.0, 0.0), (12.0, -7.0, -45.0)),
-    ]
-    for ci, (mission, N, airframe, goal, start) in enumerate(spec):
-        rng = np.random.default_rng(4200 + ci)
-        ac15 = np.array(read_param_values(os.path.join(REF, "aircraft", airframe + ".param")))
-        lim8 = np.array(read_param_values(os.path.join(REF, "problems", mission, "limits.param")))
-        assert len(ac15) == 15 and len(lim8) == 8
+    rng = np.random.default_rng((4200 if kind == "small" else 7700) + ci)
+    ac15 = np.array(read_param_values(os.path.join(REF, "aircraft", airframe + ".param")))
+    lim8 = np.array(read_param_values(os.path.join(REF, "problems", mission, "limits.param")))
+    assert len(ac15) == 15 and len(lim8) == 8
+    if kind == "small":
         if ci >= 2:     # perturbed air-frame coefficients: mass, area, e, AR, Cd0 all away from the shipped values
             ac15[[0, 2, 3, 4, 5]] *= rng.uniform(0.8, 1.25, 5)
         # non-shipped gains, all different and non-zero: kT kp kv ka kdt
         gains = np.array([0.37, 5.3, 2.9, 0.0, 1.7]) * (1.0 + 0.1 * ci)
-        o = RefProblem(mission, N, aircraft_members(ac15), gains, lim8, goal, start)
-        tag = "c%d_" % ci
-        it.call(o, "InitialCond")
-        x0 = np.array(o.x)
-        it.call(o, "setLimits")
-        it.call(o, "countG", o.x)
-        neG = o.neG
-        out[tag + "meta"] = np.array([0 if mission == "S10" else 1, N, o.n, o.neF, neG])
-        out[tag + "ac15"], out[tag + "gains"], out[tag + "lim8"] = ac15, gains, lim8
-        out[tag + "goal"], out[tag + "start"] = np.array(goal), np.array(start)
-        out[tag + "chi_d"] = np.array([o.chi_d])
-        out[tag + "x0"] = x0
-        out[tag + "xlow"], out[tag + "xupp"] = np.array(o.xlow), np.array(o.xupp)
-        out[tag + "Flow"], out[tag + "Fupp"] = np.array(o.Flow), np.array(o.Fupp)
-        out[tag + "iGfun"] = np.array(o.iGfun[:neG], dtype=np.int32)
-        out[tag + "jGvar"] = np.array(o.jGvar[:neG], dtype=np.int32)
+    else:
+        gains = np.array(read_param_values(os.path.join(REF, "problems", mission, "gains.param")))
+        assert len(gains) == 5
+    o = RefProblem(mission, N, aircraft_members(ac15), gains, lim8, goal, start)
+    it.call(o, "InitialCond")
+    x0 = np.array(o.x)
+    it.call(o, "setLimits")
+    it.call(o, "countG", o.x)
+    neG = o.neG
+    out[tag + "meta"] = np.array([0 if mission == "S10" else 1, N, o.n, o.neF, neG])
+    out[tag + "ac15"], out[tag + "gains"], out[tag + "lim8"] = ac15, gains, lim8
+    out[tag + "goal"], out[tag + "start"] = np.array(goal), np.array(start)
+    out[tag + "chi_d"] = np.array([o.chi_d])
+    out[tag + "x0"] = x0
+    out[tag + "xlow"], out[tag + "xupp"] = np.array(o.xlow), np.array(o.xupp)
+    out[tag + "Flow"], out[tag + "Fupp"] = np.array(o.Flow), np.array(o.Fupp)
+    out[tag + "iGfun"] = np.array(o.iGfun[:neG], dtype=np.int32)
+    out[tag + "jGvar"] = np.array(o.jGvar[:neG], dtype=np.int32)
+    if kind == "small":
         out[tag + "ioutput"] = np.frombuffer(it.output.files.get("Ioutput.txt", "").encode(), dtype=np.uint8)
+    print("  %s %s N=%d %s: pattern after %.0f s" % (tag, mission, N, airframe, time.time() - t_start), flush=True)
 
-        # test points: (wind kind, x)
+    # test points: (wind kind, x, table)
+    if kind == "small":
         grid_v = rng.uniform(-6, 6, (4, 4, 4))
         grid = dict(origin=(-260.0 + start[1], -240.0 + start[0], -30.0), spacing=(150.0, 150.0, 150.0), datum=(10.0, -20.0, 5.0))
         points = [("shear", x0.copy(), None), ("shear", perturbed(x0, N, rng), None)]
@@ -192,36 +201,169 @@ def main():
             tbl[:3] *= 10.0
             points.append(("table", perturbed(x0, N, rng), tbl))
         points.append(("grid", perturbed(x0, N, rng), None))
-        X, Fs, Gs, kinds, tables, wouts = [], [], [], [], [], []
-        for kind, x, tbl in points:
-            if kind == "shear":
-                o.Pwindmodel = 1
-            elif kind == "table":
-                o.set_wind_table(tbl)
-            else:
-                o.set_grid(grid_v, grid["origin"], grid["spacing"], grid["datum"])
-            xl = [float(t) for t in x]
-            F, G = [0.0] * o.neF, [0.0] * neG
-            # src/DefineFG.cpp:24-37
-            it.call(o, "modelWind", xl)
-            it.call(o, "computeF", xl, F)
-            it.call(o, "computeG", xl, G)
-            X.append(x); Fs.append(F); Gs.append(G)
-            kinds.append({"shear": 1, "table": 99, "grid": 3}[kind])
-            tables.append(np.array([getattr(o, nm) for nm in ("u", "v", "w", "du_dx", "du_dy", "du_dz", "dv_dx", "dv_dy", "dv_dz", "dw_dx", "dw_dy", "dw_dz")]))
-            wouts.append(it.output.files.get("Woutput.txt", ""))
-        out[tag + "X"], out[tag + "F"], out[tag + "G"] = np.array(X), np.array(Fs), np.array(Gs)
-        out[tag + "windmodel"] = np.array(kinds)
+    else:
+        points = [("shear", x0.copy(), None), ("shear", perturbed(x0, N, rng), None), ("none", perturbed(x0, N, rng), None)]
+    X, Fs, Gs, kinds, tables, wouts = [], [], [], [], [], []
+    for pk, x, tbl in points:
+        if pk == "shear":
+            o.Pwindmodel = 1
+        elif pk == "none":
+            o.Pwindmodel = 0                        # src/problem.cpp:477-492
+        elif pk == "table":
+            o.set_wind_table(tbl)
+        else:
+            o.set_grid(grid_v, grid["origin"], grid["spacing"], grid["datum"])
+        xl = [float(t) for t in x]
+        F, G = [0.0] * o.neF, [0.0] * neG
+        # src/DefineFG.cpp:24-37
+        it.call(o, "modelWind", xl)
+        it.call(o, "computeF", xl, F)
+        it.call(o, "computeG", xl, G)
+        X.append(x); Fs.append(F); Gs.append(G)
+        kinds.append({"none": 0, "shear": 1, "table": 99, "grid": 3}[pk])
+        tables.append(np.array([getattr(o, nm) for nm in WIND_NAMES]))
+        wouts.append(it.output.files.get("Woutput.txt", ""))
+    out[tag + "X"], out[tag + "F"], out[tag + "G"] = np.array(X), np.array(Fs), np.array(Gs)
+    out[tag + "windmodel"] = np.array(kinds)
+    if kind == "small":
         out[tag + "wind"] = np.array(tables)          # the twelve member vectors as modelWind left them (ENU)
         out[tag + "grid_v"] = grid_v
         out[tag + "grid_geom"] = np.array(list(grid["origin"]) + list(grid["spacing"]) + list(grid["datum"]))
         out[tag + "woutput0"] = np.frombuffer(wouts[0].encode(), dtype=np.uint8)   # Woutput.txt of the first point
-        cases.append(tag)
-        print("case %d %s N=%d %s: n=%d neF=%d neG=%d, %d points, %d interpreted calls, %.0f s" %
-              (ci, mission, N, airframe, o.n, o.neF, neG, len(points), it.calls, time.time() - t_start), flush=True)
-    out["cases"] = np.array(cases)
-    np.savez_compressed(OUT, **out)
-    print("wrote", OUT, os.path.getsize(OUT), "bytes")
+    print("case %s %s N=%d %s: n=%d neF=%d neG=%d, %d points, %d interpreted calls, %.0f s" %
+          (tag, mission, N, airframe, o.n, o.neF, neG, len(points), it.calls, time.time() - t_start), flush=True)
+    return tag, out
+
+
+def decode_pattern(iG, jG, neF, nb, pF=8, px=11):
+    """(Fnum, xnum, tf, tx) that countG files for pattern entry (ii, jj): src/problem.cpp:826-849, and :883-910 for the
+    dt slot of a dynamics row (re-targeted to tx = tf).  C integer division truncates toward zero.  Used by the "long"
+    set only, where running countG's neF x n probe itself is out of reach; checked there against the arrays the
+    interpreted countG leaves behind at a small ts."""
+    def cdiv(a, b):
+        return int(a / b)
+    Fs, xs, tfs, txs = [], [], [], []
+    for ii, jj in zip(iG, jG):
+        ii, jj = int(ii), int(jj)
+        Fnum = ii % pF
+        if Fnum == 0 and ii != 0:
+            Fnum = pF
+        tf = cdiv(ii - 1, pF)
+        if ii >= neF - nb:
+            Fnum = pF + nb - (neF - 1 - ii)
+        xnum = px if jj == 0 else (jj - 1) % px
+        tx = cdiv(jj - 1, px)
+        if jj == 0 and 1 <= Fnum <= pF:
+            tx = tf
+        Fs.append(float(Fnum)); xs.append(float(xnum)); tfs.append(float(tf)); txs.append(float(tx))
+    return Fs, xs, tfs, txs
+
+
+def closed_form_pattern(mission, N):
+    """SURVEY.md section 8's closed form of the pattern (row-major (row, col) order), restated in oracle/oracle.py."""
+    sys.path.insert(0, os.path.dirname(HERE))
+    from oracle import oracle as O
+    return O.pattern(mission, N) if hasattr(O, "pattern") else O.Problem(mission, "tempest", N=N).pattern()
+
+
+def run_long(job):
+    """BASELINE configs[2] (S10, skywalker, ts = 2000).  countG's probe (352 million gradient calls) is out of reach, so
+    the pattern comes from the closed form -- equal to countG's at every ts the other sets ran it for -- and the four
+    sparse arrays from decode_pattern; InitialCond, setLimits, modelWind, computeF and computeG (214 037 gradient calls
+    per point) are the reference's.  Stored: x, F, every 53rd G entry, and three sums over G."""
+    t_start = time.time()
+    it = cinterp.Interp([open(os.path.join(REF, "src", f), errors="replace").read() for f in SRC_FILES])
+    mission, N, airframe, goal, start, tag = (job[k] for k in ("mission", "N", "airframe", "goal", "start", "tag"))
+    nb = 11 if mission == "S10" else 12
+    # the decode rule against an interpreted countG
+    small = RefProblem(mission, 12, aircraft_members(np.array(read_param_values(os.path.join(REF, "aircraft", airframe + ".param")))),
+                       np.array(read_param_values(os.path.join(REF, "problems", mission, "gains.param"))),
+                       np.array(read_param_values(os.path.join(REF, "problems", mission, "limits.param"))), goal, start)
+    it.call(small, "InitialCond"); it.call(small, "countG", small.x)
+    iGs, jGs = closed_form_pattern(mission, 12)
+    assert small.neG == len(iGs) and list(iGs) == small.iGfun[:small.neG] and list(jGs) == small.jGvar[:small.neG]
+    dec = decode_pattern(iGs, jGs, small.neF, nb)
+    for got, name in zip(dec, ("F_sparse", "x_sparse", "tf_sparse", "tx_sparse")):
+        assert got == [float(v) for v in getattr(small, name)[:small.neG]], name
+    print("  decode rule equals the interpreted countG's arrays at ts = 12 (%d entries), %.0f s" % (small.neG, time.time() - t_start), flush=True)
+
+    rng = np.random.default_rng(9900)
+    ac15 = np.array(read_param_values(os.path.join(REF, "aircraft", airframe + ".param")))
+    lim8 = np.array(read_param_values(os.path.join(REF, "problems", mission, "limits.param")))
+    gains = np.array(read_param_values(os.path.join(REF, "problems", mission, "gains.param")))
+    iG, jG = closed_form_pattern(mission, N)
+    neG = len(iG)
+    o = RefProblem(mission, N, aircraft_members(ac15), gains, lim8, goal, start, lenG=neG)
+    it.call(o, "InitialCond")
+    x0 = np.array(o.x)
+    it.call(o, "setLimits")
+    o.neG = neG
+    o.iGfun, o.jGvar = [int(v) for v in iG], [int(v) for v in jG]
+    o.F_sparse, o.x_sparse, o.tf_sparse, o.tx_sparse = decode_pattern(iG, jG, o.neF, nb)
+    out = {tag + "meta": np.array([0 if mission == "S10" else 1, N, o.n, o.neF, neG]), tag + "goal": np.array(goal),
+           tag + "x0": x0, tag + "xlow": np.array(o.xlow), tag + "xupp": np.array(o.xupp),
+           tag + "Flow": np.array(o.Flow), tag + "Fupp": np.array(o.Fupp)}
+    X, Fs, Gsamp, Gsums = [], [], [], []
+    weights = 1.0 + (np.arange(neG) % 1009) / 1009.0            # position-dependent: a permuted G changes this sum
+    for x in (x0.copy(), perturbed(x0, N, rng)):
+        xl = [float(t) for t in x]
+        F, G = [0.0] * o.neF, [0.0] * neG
+        it.call(o, "modelWind", xl)
+        it.call(o, "computeF", xl, F)
+        it.call(o, "computeG", xl, G)
+        G = np.array(G)
+        X.append(x); Fs.append(F); Gsamp.append(G[::53])
+        Gsums.append([np.nansum(G), np.nansum(np.abs(G)), np.nansum(G * weights), float(np.isnan(G).sum())])
+        print("  %s point done, %d interpreted calls, %.0f s" % (tag, it.calls, time.time() - t_start), flush=True)
+    out[tag + "X"], out[tag + "F"] = np.array(X), np.array(Fs)
+    out[tag + "G_every_53rd"], out[tag + "G_sums"] = np.array(Gsamp), np.array(Gsums)
+    return tag, out
+
+
+SMALL = [  # (mission, N, airframe, goal (east, north, up, radius), start)
+    ("S10", 6, "tempest", (400.0, 0.0, 70.0, 100.0), (0.0, 0.0, 0.0)),
+    ("G7", 6, "tempest", (400.0, 0.0, 70.0, 0.0), (0.0, 0.0, 0.0)),
+    ("S10", 9, "skywalker", (250.0, -120.0, 70.0, 80.0), (15.0, -25.0, -40.0)),
+    ("G7", 9, "skywalker", (300.0, 200.0, 70.0, 0.0), (-20.0, 30.0, -55.0)),
+    # odd ts: c0 is odd, so the product takes its scalar-store kernels; 20 nodes: more than one 16-node store group
+    ("S10", 13, "tempest", (380.0, 40.0, 70.0, 120.0), (5.0, 8.0, -35.0)),
+    ("G7", 20, "tempest", (350.0, -150.0, 70.0, 0.0), (12.0, -7.0, -45.0)),
+]
+AIRFRAMES = ["tempest", "skywalker", "tempest_eric", "tempest_wences", "tempest_will"]
+# the repository as shipped (ts = 100, shipped gains / limits / air frames), arguments `0 0 100 400 0 70 <radius> <airframe> <mission>`
+# (src/arguments.cpp:36-44); plus BASELINE configs[1]'s ts = 200 once per mission
+SHIPPED = [(m, 100, a, (400.0, 0.0, 70.0, 100.0 if m == "S10" else 0.0), (0.0, 0.0, 0.0)) for m in ("S10", "G7") for a in AIRFRAMES] + \
+          [("S10", 200, "tempest", (400.0, 0.0, 70.0, 100.0), (0.0, 0.0, 0.0)), ("G7", 200, "tempest", (400.0, 0.0, 70.0, 0.0), (0.0, 0.0, 0.0))]
+
+
+def main():
+    import argparse
+    import multiprocessing as mp
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--set", choices=["small", "shipped", "long"], default="small")
+    ap.add_argument("--workers", type=int, default=6)
+    args = ap.parse_args()
+    t_start = time.time()
+    if args.set == "long":
+        tag, out = run_long(dict(tag="l0_", mission="S10", N=2000, airframe="skywalker", goal=(400.0, 0.0, 70.0, 100.0), start=(0.0, 0.0, 0.0)))
+        out["cases"] = np.array([tag])
+        np.savez_compressed(OUT_LONG, **out)
+        print("wrote", OUT_LONG, os.path.getsize(OUT_LONG), "bytes, %.0f s" % (time.time() - t_start))
+        return
+    spec = SMALL if args.set == "small" else SHIPPED
+    prefix = "c" if args.set == "small" else "s"
+    jobs = [dict(tag="%s%d_" % (prefix, ci), ci=ci, mission=m, N=N, airframe=a, goal=g, start=st, kind=args.set)
+            for ci, (m, N, a, g, st) in enumerate(spec)]
+    order = sorted(range(len(jobs)), key=lambda i: -jobs[i]["N"])          # longest first
+    with mp.Pool(min(args.workers, len(jobs))) as pool:
+        done = dict(pool.imap_unordered(run_case, [jobs[i] for i in order]))
+    out = {}
+    for j in jobs:
+        out.update(done[j["tag"]])
+    out["cases"] = np.array([j["tag"] for j in jobs])
+    path = OUT if args.set == "small" else OUT_SHIPPED
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes, %.0f s" % (time.time() - t_start))
 
 
 if __name__ == "__main__":
