@@ -415,6 +415,12 @@ def main():
             if args.pattern == "reference" and args.mission != "mixed":
                 line["next_compact_pattern"] = compact_side_run(tol_amd, torch, args, B, local)
                 line["two_batches_two_streams"] = two_streams_record(tol_amd, torch, args, B, local)
+                # the same shape at four times the batch (3.5 GB of F + G): what a launch reaches once its fill and
+                # drain are a smaller share; a side record, the headline batch stays as it was
+                big = device_record(tol_amd, torch, 9, "headline shape at %d trajectories per GPU" % (4 * B), args.mission,
+                                    (args.aircraft,), args.ts, 4 * B, args.dtype, 30, local, 2)
+                del big["config"]
+                line["headline_shape_larger_batch"] = big
         print(json.dumps(line), flush=True)
 
     if world > 1:

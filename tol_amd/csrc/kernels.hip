@@ -526,6 +526,9 @@ __device__ __forceinline__ void tile_body(const FgArgs &a, T *lds, int item, int
     TOLFG_REALTIME(a, 7);
     TOLFG_WHERE(a, 9);
     TOLFG_STAMP(a, 0);
+#if defined(TOLFG_PRIO) && TOLFG_PRIO == 2
+    __builtin_amdgcn_s_setprio(3);
+#endif
     {
         const int nvec = (NI * cnt + 9 + VEC - 1) / VEC;
         const T *xwin = xrow + NI * k0;
@@ -632,6 +635,11 @@ __device__ __forceinline__ void tile_body(const FgArgs &a, T *lds, int item, int
         __syncthreads();
         TOLFG_STAMP(a, 3);
         __builtin_amdgcn_sched_barrier(0);
+#if defined(TOLFG_PRIO) && TOLFG_PRIO == 1        // experiment: waves in their store phase issue first
+        __builtin_amdgcn_s_setprio(3);
+#elif defined(TOLFG_PRIO) && TOLFG_PRIO == 2      // experiment: waves still loading / computing issue first
+        __builtin_amdgcn_s_setprio(0);
+#endif
         if (!(TOLFG_VARIANT(a) & 2048)) stream_slabs<T, PAT, GV, NT>(lds, Grow + a.c0[ms] + (long)SLABN * k0, cnt, lane);
         TOLFG_STAMP(a, 4);
     }

@@ -27,3 +27,6 @@ if "two_batches_two_streams" in d:
     c = d["two_batches_two_streams"]
     print("  two batches on two streams: %.1f us per evaluation, %.4g node-evals/s = %.3f of peak (whole wall time)"
           % (c["us_per_evaluation"], c["node_evals_per_s"], c["frac_of_hbm_peak"]))
+if "headline_shape_larger_batch" in d:
+    c = d["headline_shape_larger_batch"]
+    print("  %s: evaluation %.1f us = %.3f of peak, whole step %.4g node-evals/s" % (c["workload"], c["eval_us"], c["frac_of_hbm_peak"], c["node_evals_per_s"]))

@@ -17,6 +17,8 @@
 //   mode 14: mode 4 (S KiB per wave, in order) but every store instruction is spread over 64/GRP sub-regions of the wave's
 //            region: lanes [g*GRP, (g+1)*GRP) write GRP*16 contiguous bytes of sub-region g (one instruction touches
 //            64/GRP places S/(64/GRP) KiB apart instead of one contiguous KiB)
+//   mode 15: mode 4's shape with the store's cache-policy bits chosen by GRP: 0 none, 1 nt, 2 sc0, 3 sc1, 4 sc0 sc1,
+//            5 nt sc0, 6 nt sc1, 7 nt sc0 sc1
 //   mode 10: mode 7 where every wave first reads 1 KiB and idles `delay` x 64 s_sleep(8) (load -> compute -> store)
 // LDS bytes per block (dynamic) limit the occupancy like the real kernel's 22 KB does.
 //
@@ -96,6 +98,19 @@ __global__ __launch_bounds__(64) void wr(vec2 *out, int S, int grp, int delay, l
         const long sub_len = (long)S * 64 / subs;
         vec2 *base = out + id * S * 64 + (lane / LG) * sub_len + lane % LG;
         for (int i = 0; i < S; i++) __builtin_nontemporal_store(v, &base[(long)i * LG]);
+    } else if (MODE == 15) {
+        vec2 *base = out + id * S * 64;
+#define WR_POLICY(bits) for (int i = 0; i < S; i++) asm volatile("global_store_dwordx4 %0, %1, off " bits :: "v"(&base[(long)i * 64 + lane]), "v"(v) : "memory")
+        switch (grp) {
+        case 0: WR_POLICY(""); break;
+        case 1: WR_POLICY("nt"); break;
+        case 2: WR_POLICY("sc0"); break;
+        case 3: WR_POLICY("sc1"); break;
+        case 4: WR_POLICY("sc0 sc1"); break;
+        case 5: WR_POLICY("sc0 nt"); break;
+        case 6: WR_POLICY("sc1 nt"); break;
+        default: WR_POLICY("sc0 sc1 nt"); break;
+        }
     } else if (MODE == 13) {
         const long seg = (id * 7919L) % nblocks;
         vec2 *base = out + seg * S * 64;
@@ -140,6 +155,7 @@ int main(int argc, char **argv)
         if (mode == 8) hipLaunchKernelGGL(wrg<8>, dim3(nblocks), dim3(64 * grp), lds, 0, d, S, grp, delay, nblocks);
         if (mode == 11) hipLaunchKernelGGL(wr<11>, dim3(nblocks), dim3(64), lds, 0, d, S, grp, delay, nblocks);
         if (mode == 14) hipLaunchKernelGGL(wr<14>, dim3(nblocks), dim3(64), lds, 0, d, S, grp, delay, nblocks);
+        if (mode == 15) hipLaunchKernelGGL(wr<15>, dim3(nblocks), dim3(64), lds, 0, d, S, grp, delay, nblocks);
         if (mode == 13) hipLaunchKernelGGL(wr<13>, dim3(nblocks), dim3(64), lds, 0, d, S, grp, delay, nblocks);
         if (mode == 10) hipLaunchKernelGGL(wrg<10>, dim3(nblocks), dim3(64 * grp), lds, 0, d, S, grp, delay, nblocks);
     };
