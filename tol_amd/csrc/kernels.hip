@@ -924,7 +924,13 @@ __global__ __launch_bounds__(TILE, TOLFG_MIN_WAVES_PER_SIMD) void fg_kernel(cons
 #endif
     {
         int item = blockIdx.x;
-        if (item < 8 * a.xcd_chunk) item = (item & 7) * a.xcd_chunk + (item >> 3);     // the rest (the launch's tail) in id order
+        if (item < 8 * a.xcd_chunk) {                  // the rest (the launch's tail) in id order
+            int x = item & 7;
+            if (TOLFG_VARIANT(a) & (1 << 16)) x ^= 1;              // probes (stamped build): which XCD walks which eighth
+            if (TOLFG_VARIANT(a) & (1 << 17)) x = (x + 4) & 7;
+            if (TOLFG_VARIANT(a) & (1 << 18)) x = (x + 2) & 7;
+            item = x * a.xcd_chunk + (item >> 3);
+        }
         if (item >= total_tiles(a)) return;            // the grid may be rounded up to 8 * xcd_chunk
         run_tile<T, MISSION, WIND, VEC, PAT, NT>(a, lds, item, lane);
         if (a.done) signal_done(a, (int)total_tiles(a), lane == 0);

@@ -165,6 +165,18 @@ int main(int argc, char **argv)
             sum_res += busy / (double)(t1 - t0); ncu++;
         }
         printf("\n  distinct CUs seen %d, mean resident waves per CU %.2f\n", ncu, ncu ? sum_res / ncu : 0.0);
+        // per XCD: tile waves run, when its last wave ended (us after the launch's first wave started), median wave life
+        printf("  per XCC: waves / last end us / median life us:");
+        for (int x = 0; x < 8; x++) {
+            unsigned long long last = 0; long cnt = 0; std::vector<double> lf;
+            for (long id = 0; id < blocks; id++) {
+                const unsigned long long *q = &S[(size_t)id * 10];
+                if (!q[7] || !q[8] || q[8] < q[7] || (int)((q[9] >> 32) & 7) != x) continue;
+                cnt++; last = std::max(last, q[8]); lf.push_back((double)(q[8] - q[7]) * 0.01);
+            }
+            printf("  [%d] %ld / %.1f / %.2f", x, cnt, last ? (last - t0) * 0.01 : 0.0, med(lf));
+        }
+        printf("\n");
     }
     printf("timeline (last launch): span first wave start -> last wave end %.2f us; peak %d resident tile waves (%.1f per CU); "
            "fill to 90%% of peak %.2f us; at >= 90%% for %.2f us; tail after the last 90%% moment %.2f us; mean occupancy %.0f waves = %.0f %% of peak; "
