@@ -87,3 +87,45 @@ def test_frozen_wind_jacobian_converges_only_linearly(oracle):
     _, norms, _ = gauss_newton(eval_fg, p.pattern(), p.bounds(), x, p.n, p.neF, iters=10)
     tail = [b / a for a, b in zip(norms[3:-1], norms[4:])]
     assert norms[-1] < 1e-8 and all(0.02 < r < 0.3 for r in tail), norms
+
+
+@pytest.mark.gpu
+def test_gauss_newton_on_a_batch(tolfg):
+    """The batched evaluation in the same loop: eight trajectories (five air frames, different goals and starts), one launch
+    per iteration for all of them, the linear algebra per trajectory on the host."""
+    import torch
+    N, B = 60, 8
+    names = ["tempest", "skywalker", "tempest_eric", "tempest_wences", "tempest_will"]
+    bt = tolfg.Batch("S10", names, ts=N, windmodel=tolfg.capi.WIND_NONE)
+    bt.set_trajectories([tolfg.Trajectory(aircraft=t % 5, north_goal=10.0 * t, east_goal=400.0 - 20.0 * t, radius_goal=80.0 + 5.0 * t,
+                                          xi=3.0 * t, yi=-2.0 * t, zi=-40.0 - t) for t in range(B)])
+    dX, dF, dG = bt.alloc(B)
+    bt.x0_device(dX)
+    gen = torch.Generator(device="cuda").manual_seed(12)
+    dX[:, :bt.n] += 0.01 * (torch.rand(B, bt.n, dtype=torch.float64, device="cuda", generator=gen) * 2 - 1) * (1 + dX[:, :bt.n].abs())
+    iG, jG = bt.pattern()
+    dxl, dxu = torch.empty_like(dX), torch.empty_like(dX)
+    dFl, dFu = torch.empty_like(dF), torch.empty_like(dF)
+    bt.bounds_device(dxl, dxu, dFl, dFu)
+    torch.cuda.synchronize()
+    Fl, Fu = dFl.cpu().numpy(), dFu.cpu().numpy()
+    rows = [np.flatnonzero((Fl[t, :bt.neF] == Fu[t, :bt.neF]) & (np.arange(bt.neF) > 0)) for t in range(B)]
+    history = []
+    for _ in range(8):
+        bt.eval(dX, dF, dG)
+        torch.cuda.synchronize()
+        F, G, X = dF.cpu().numpy(), dG.cpu().numpy(), dX.cpu().numpy()
+        worst = 0.0
+        for t in range(B):
+            c = F[t, rows[t]] - Fl[t, rows[t]]
+            worst = max(worst, np.abs(c).max())
+            J = np.zeros((bt.neF, bt.n))
+            J[iG, jG] = G[t, :bt.neG]
+            step, *_ = np.linalg.lstsq(J[rows[t]], c, rcond=None)
+            X[t, :bt.n] -= step
+        history.append(worst)
+        if worst < 1e-11:
+            break
+        dX.copy_(torch.from_numpy(X))
+    check_convergence(history, "batch")
+    bt.close()
