@@ -6,15 +6,17 @@ import sys
 txt = open(sys.argv[1]).read() if len(sys.argv) > 1 else sys.stdin.read()
 d = json.loads(txt.strip().splitlines()[-1])
 r = d["roofline"]
-print("value %.4g %s on %d GPU(s), %s scaling, backend %s; ms/step %.4f; evaluation %.4f ms (min %.4f) -> %.0f GB/s = %.3f of peak"
-      % (d["value"], d["unit"], d["n_gpus"], d["scaling"], d.get("backend"), d["ms_per_step"], r["kernel_ms"], r["kernel_min_ms"], r["achieved"], r["frac"]))
+print("value %.4g %s on %d GPU(s), %s scaling, backend %s; ms/step %.4f; per launch %.4f ms -> %.0f GB/s = %.3f of peak  (instrumented pass: %.4f ms, min %.4f)"
+      % (d["value"], d["unit"], d["n_gpus"], d["scaling"], d.get("backend"), d["ms_per_step"], r["kernel_ms"], r["achieved"], r["frac"],
+         r.get("instrumented_kernel_ms", float("nan")), r.get("instrumented_kernel_min_ms", r.get("kernel_min_ms", float("nan")))))
 for c in d.get("configs", []):
     if c["mode"] == "callback":
         print("  config %d callback: %.1f us/call native (%.1f via ctypes; F only %.1f) = %.3g node-evals/s  [%s]"
               % (c["config"], c["us_per_call"], c["us_per_call_via_python_ctypes"], c.get("us_per_call_needF_only", float("nan")), c["node_evals_per_s"], c["workload"]))
     else:
-        print("  config %d B=%d %s: step %.1f us, evaluation %.1f us (min %.1f) = %.0f GB/s = %.3f of peak, %.3g node-evals/s  [%s]"
-              % (c["config"], c["batch"], c["dtype"], 1e3 * c["ms_per_step"], c["eval_us"], c["eval_min_us"], c["achieved_GBs"], c["frac_of_hbm_peak"],
+        print("  config %d B=%d %s: step %.1f us, per launch %.1f us (instrumented %.1f, min %.1f) = %.0f GB/s = %.3f of peak, %.3g node-evals/s  [%s]"
+              % (c["config"], c["batch"], c["dtype"], 1e3 * c["ms_per_step"], c["eval_us"], c.get("eval_us_instrumented", float("nan")),
+                 c.get("eval_min_us_instrumented", c.get("eval_min_us", float("nan"))), c["achieved_GBs"], c["frac_of_hbm_peak"],
                  c["node_evals_per_s"], c["workload"]))
 if "cpu_baseline" in d:
     b = d["cpu_baseline"]
