@@ -184,7 +184,7 @@ int main(int argc, char **argv)
     CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    printf("| B | N | mission | dtype | max_nt -> tiles x nt | cap | fused | us/eval back to back | kernel us (dispatch events) | GB/s alg | %% of 8 TB/s | check |\n|---|---|---|---|---|---|---|---|---|---|---|---|\n");
+    printf("| B | N | mission | dtype | max_nt -> tiles x nt | cap | fused | us/eval back to back, per-dispatch events | kernel us (dispatch events) | us/eval back to back, uninstrumented | GB/s alg (uninstrumented) | %% of 8 TB/s | check |\n|---|---|---|---|---|---|---|---|---|---|---|---|---|\n");
     for (int i = 1; i < argc; i++) {
         if (!strncmp(argv[i], "reps=", 5)) { reps = atoi(argv[i] + 5); continue; }
         if (!strncmp(argv[i], "xbuf=", 5)) { xbuf = atoi(argv[i] + 5); bf.release(); bf.sh = Shape{}; continue; }
@@ -234,6 +234,17 @@ int main(int argc, char **argv)
         CK(hipEventElapsedTime(&ms, e0, e1));
         double kern_us = 0;
         for (int r = 0; r < reps; r++) { float k; CK(hipEventElapsedTime(&k, kev[2 * r], kev[2 * r + 1])); kern_us += 1e3 * k / reps; }
+        // the same launches without per-dispatch events (they cost 4-16 us per launch, profiles/r02_event_cost.md)
+        CK(hipEventRecord(e0, st));
+        for (int r = 0; r < reps; r++) {
+            tolfg::FgArgs ar = make_args(bf, v[2], v[3], v[4], r, bf.dF, bf.dG);
+            CK(tolfg::launch_fg(ar, sh.mission, tolfg::WIND_SHEAR, sh.dtype, vec, st));
+        }
+        CK(hipEventRecord(e1, st));
+        CK(hipEventSynchronize(e1));
+        float ms_plain;
+        CK(hipEventElapsedTime(&ms_plain, e0, e1));
+        const double us_plain = 1e3 * ms_plain / reps;
         // repeat of the check after the timed launches: the counters must have been left at zero
         CK(hipMemsetAsync(bf.dF, 0xff, bf.es() * sh.B * sh.ldf, st));
         CK(hipMemsetAsync(bf.dG, 0xff, bf.es() * sh.B * sh.ldg, st));
@@ -245,10 +256,10 @@ int main(int argc, char **argv)
         const double us = 1e3 * ms / reps;
         char tailtxt[48] = "";
         if (a.tail_count) snprintf(tailtxt, sizeof tailtxt, " tail %d x (%d x %d)", a.tail_count, a.tail_tiles, a.tail_nt);
-        printf("| %d | %d | %s | %s | %d -> %d x %d | %d | %d%s%s%s | %.2f | %.2f | %.0f | %.1f | %s |\n", sh.B, sh.N,
+        printf("| %d | %d | %s | %s | %d -> %d x %d | %d | %d%s%s%s | %.2f | %.2f | %.2f | %.0f | %.1f | %s |\n", sh.B, sh.N,
                sh.mission == 0 ? "S10" : (sh.mission == 1 ? "G7" : "mixed"), sh.dtype == 0 ? "f64" : "f32", v[2], a.tiles, a.nt, v[3], v[4],
-               bf.nt ? " nt" : " plain", a.persist ? " persist" : (bf.xcd ? (bf.xcdpct == 100 ? " xcd" : " xcd-part") : ""), tailtxt, us, kern_us,
-               bytes / (1e3 * us), 100.0 * bytes / (1e3 * us) / 8000.0, (bad || bad2) ? "MISMATCH" : "ok");
+               bf.nt ? " nt" : " plain", a.persist ? " persist" : (bf.xcd ? (bf.xcdpct == 100 ? " xcd" : " xcd-part") : ""), tailtxt, us, kern_us, us_plain,
+               bytes / (1e3 * us_plain), 100.0 * bytes / (1e3 * us_plain) / 8000.0, (bad || bad2) ? "MISMATCH" : "ok");
         fflush(stdout);
     }
     bf.release();
