@@ -3,6 +3,7 @@
 (mission = b mod 2, air-frame = b mod 5 over all five .param files, ts = 200), evaluated on the GPU
 in fp64 and in fp32; reports max abs / max scaled error of fp32 against fp64 per row class, and of
 fp64 against the CPU oracle on a subset.  Run on the GPU box; writes a markdown table to stdout.
+(Kept under tests/ because it checks against oracle/, which only test code may use.)
 
 scaled error = |a - b| / (1 + |b|), the measure the parity tests use.
 """

@@ -14,7 +14,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))             # lives under tests/: only test code may use oracle/
 from oracle import oracle as O          # noqa: E402
 from helpers import random_wind_table   # noqa: E402
 

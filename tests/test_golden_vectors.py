@@ -1,4 +1,4 @@
-"""Committed vectors (tests/golden/oracle_vectors.npz, written by tools/make_golden.py from this
+"""Committed vectors (tests/golden/oracle_vectors.npz, written by tests/make_golden.py from this
 repo's oracle -- see that script for provenance): the oracle must still reproduce them bitwise on
 CPU, and the HIP path must match them on the GPU box."""
 import os
@@ -10,7 +10,7 @@ import pytest
 from helpers import assert_close
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tools"))
+sys.path.insert(0, HERE)
 from make_golden import CASES   # noqa: E402
 
 VEC = np.load(os.path.join(HERE, "golden", "oracle_vectors.npz"))

@@ -15,5 +15,5 @@ echo "== $pat (rep $rep)"
 timeout -k 10 200 python bench.py --pattern $pat --steps 100 --no-cpu-baseline --no-configs 2>/dev/null | one
 done
 done
-echo "== fp32 sweep"; timeout -k 10 300 python tools/fp32_sweep.py > $O/fp32_sweep.md 2>$O/fp32.err; echo "exit $?"; tail -3 $O/fp32.err; cat $O/fp32_sweep.md
+echo "== fp32 sweep"; timeout -k 10 300 python tests/fp32_sweep.py > $O/fp32_sweep.md 2>$O/fp32.err; echo "exit $?"; tail -3 $O/fp32.err; cat $O/fp32_sweep.md
 echo "== rehearse 2 ranks (gloo, one GPU)"; bash tools/rehearse_ranks.sh 2>&1 | tail -3 | cut -c1-300

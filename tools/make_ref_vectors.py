@@ -260,10 +260,33 @@ def decode_pattern(iG, jG, neF, nb, pF=8, px=11):
 
 
 def closed_form_pattern(mission, N):
-    """SURVEY.md section 8's closed form of the pattern (row-major (row, col) order), restated in oracle/oracle.py."""
-    sys.path.insert(0, os.path.dirname(HERE))
-    from oracle import oracle as O
-    return O.pattern(mission, N) if hasattr(O, "pattern") else O.Problem(mission, "tempest", N=N).pattern()
+    """SURVEY.md section 8's closed form of the pattern, in row-major (row, column) order: the objective row, per node
+    k and state r the 13 entries (8k+r, 0), (8k+r, 11k+1+m) m = 0..10, (8k+r, 11(k+1)+r), then the boundary rows.
+    Asserted equal to what the interpreted countG finds at a small ts before it is used (run_long)."""
+    iG, jG = [], []
+
+    def add(i, cols):
+        for j in cols:
+            iG.append(i); jG.append(j)
+    if mission == "S10":
+        add(0, [0] + [c for k in range(N + 1) for c in (11 * k + 1, 11 * k + 2, 11 * k + 11)])
+    else:
+        add(0, [0, 1, 2] + [11 * k + 11 for k in range(N)] + [11 * N + 1, 11 * N + 2, 11 * N + 11])
+    for k in range(N):
+        for r in range(1, 9):
+            add(8 * k + r, [0] + [11 * k + 1 + m for m in range(11)] + [11 * (k + 1) + r])
+    base = 8 * N + 1
+    if mission == "S10":
+        for b in range(11):
+            add(base + b, [0, 1 + b, 11 * N + 1 + b])
+    else:
+        for b in range(12):
+            fnum = 9 + b
+            if fnum in (9, 10, 20):
+                add(base + b, [0, 1, 2, 11 * N + 1, 11 * N + 2])
+            else:
+                add(base + b, [0, fnum - 8, 11 * N + fnum - 8])
+    return iG, jG
 
 
 def run_long(job):
