@@ -26,7 +26,8 @@ int main(int argc, char **argv)
     const int N = argc > 2 ? atoi(argv[2]) : 200;
     const int reps = argc > 3 ? atoi(argv[3]) : 30;
     const int variant = argc > 4 ? atoi(argv[4]) : 0;
-    const int n = 11 * (N + 1) + 1, neF = 8 * N + 12, neG = 107 * N + 37;
+    const int pattern = argc > 9 ? atoi(argv[9]) : 0;        // 1 = compact pattern (46-entry slabs)
+    const int n = 11 * (N + 1) + 1, neF = 8 * N + 12, neG = pattern ? (3 * N + 4) + 46 * N + 22 : 107 * N + 37;
     const long ldx = (n + 1) & ~1L, ldf = (neF + 1) & ~1L, ldg = (neG + 1) & ~1L;
 
     std::vector<double> X((size_t)B * ldx);
@@ -70,6 +71,7 @@ int main(int argc, char **argv)
     a.X = dX; a.ldx = ldx; a.F = dF; a.ldf = ldf; a.G = dG; a.ldg = ldg; a.wind = nullptr; a.traj = dT;
     a.B = B; a.N = N; a.tiles = tiles; a.nt = nt; a.partial = dP; a.obj = nullptr; a.c0[0] = 3 * N + 4; a.c0[1] = N + 6; a.needF = 1; a.needG = 1;
     a.kT[0] = 0; a.kp[0] = 8; a.kv[0] = 0; a.kdt[0] = 1;
+    a.pattern = pattern;
 
     a.ac[0] = tolfg::AcCoef{1.0 / 6.1228, 1.2682 * 0.6316 / (2 * 6.1228), 0.03, 1.0 / (16.4457 * M_PI * 0.9693)};
     a.stamps = dS; a.variant = variant;
