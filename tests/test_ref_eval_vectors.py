@@ -150,13 +150,15 @@ def test_hip_path_matches_the_reference_evaluation(tolfg, oracle, tmp_path, tag)
             cwd = os.getcwd()
             os.chdir(tmp_path)
             try:
-                pd.define_fg(X[i])
+                Fd, Gd, _ = pd.define_fg(X[i])
             finally:
                 os.chdir(cwd)
             pd.close()
             assert (tmp_path / "Woutput.txt").read_bytes() == z[tag + "woutput0"].tobytes()
-            for name, cnt in (("Xoutput.txt", p.n), ("Foutput.txt", p.neF), ("Goutput.txt", p.neG)):
-                assert len((tmp_path / name).read_text().split()) == cnt
+            # the other three dumps: one value per line as "%.14f" (src/DefineFG.cpp:16-21, 29-34, 41-46); x is the input,
+            # so that file must equal the reference's byte for byte, F and G are this call's own results in that format
+            for name, vals in (("Xoutput.txt", X[i]), ("Foutput.txt", Fd), ("Goutput.txt", Gd)):
+                assert (tmp_path / name).read_text() == "".join("%.14f\n" % v for v in vals), name
         F, G, st = p.define_fg(X[i])
         assert st == 1
         undefined = np.isnan(Gr[i])
