@@ -98,3 +98,38 @@ def test_batch_compact_equals_reference_pattern_values(tolfg, oracle, mission, d
     if dtype == "f64":
         for t in range(B):
             assert_close(out["compact"][1][t], ops[t].eval(X[t])[1][idx], what=f"compact batch G[{t}]")
+
+
+@pytest.mark.gpu
+def test_batch_that_changes_launch_form_between_evaluations(tolfg, oracle):
+    """The compact pattern takes the two-launch form when its outputs exceed the Infinity Cache (plan.cpp) and the
+    single-launch form below; the two forms use the objective-partial slots differently (values left behind vs slots
+    that must be "empty": batch::eval refills them when the form changes).  One batch object evaluated large, small, large,
+    small with alternating inputs must give the right objectives each time.  (A slot left non-empty only matters when a
+    partial's store is not yet visible to the finalizing wave, which this test cannot force; it guards the switching itself.)"""
+    import torch
+    N, B = 200, 2400                                   # 2400 x 91.5 KB = 220 MB of F + G: beyond the 192 MiB threshold
+    bt = tolfg.Batch("S10", ["tempest", "skywalker"], ts=N, pattern="compact")
+    bt.set_trajectories([tolfg.Trajectory(aircraft=t % 2, Vref=1.0 + 0.001 * t, radius_goal=90.0 + 0.01 * t) for t in range(B)])
+    dX, dF, dG = bt.alloc(B)
+    bt.x0_device(dX)
+    gen = torch.Generator(device="cuda").manual_seed(21)
+    dX[:, 1:bt.n] += 0.01 * torch.randn(B, bt.n - 1, dtype=torch.float64, device="cuda", generator=gen)
+    # two different inputs alternate, so that a slot left over from the previous evaluation holds a WRONG value
+    dX2 = dX.clone()
+    dX2[:, 1::11] += 7.0                                # every node 7 m further north: the objective's sum of (r - R)^2 changes
+    small = 48
+    ref = {}
+    for which, X in enumerate((dX, dX2)):
+        for t in (0, 1, 17, small - 1, B - 1):
+            o = oracle.Problem("S10", ["tempest", "skywalker"][t % 2], N=N, Vref=1.0 + 0.001 * t, radius_goal=90.0 + 0.01 * t)
+            ref[(which, t)] = o.eval(X[t, :bt.n].cpu().numpy())[0]
+    for i, Bnow in enumerate((B, small, B, small, small)):
+        dF.fill_(float("nan"))
+        bt.eval((dX, dX2)[i & 1], dF, dG, B=Bnow)
+        torch.cuda.synchronize()
+        F = dF.cpu().numpy()
+        for (which, t), Fo in ref.items():
+            if which == (i & 1) and t < Bnow:
+                assert_close(F[t, :bt.neF], Fo, what=f"evaluation {i} B={Bnow} trajectory {t}")
+    bt.close()

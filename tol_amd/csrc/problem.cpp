@@ -287,6 +287,7 @@ void batch::eval(int B, const void *dX, long ldx, void *dF, long ldf, void *dG, 
         // fused path: every slot starts empty and is emptied again by the wave that read it
         check(hipMemsetD32(reinterpret_cast<hipDeviceptr_t>(d_partial_), kEmptySlotWord, 4 * (size_t)W), "hipMemsetD32(partial)");
         partial_cap_ = W;
+        partial_dirty_ = false;
     }
     if (B > counter_cap_) {        // arrival counters of the fused path (+1: departures): zero between launches
         check(hipSetDevice(device_), "hipSetDevice");
@@ -299,6 +300,14 @@ void batch::eval(int B, const void *dX, long ldx, void *dF, long ldf, void *dG, 
     a.partial = d_partial_;
     a.counter = d_counter_;
     a.fused = ((fused_forced_ >= 0 ? fused_forced_ : lp.fused) || done) ? 1 : 0;   // a completion word needs the single-launch form
+    // the two-launch form leaves its partial sums in the slots; the single-launch form polls for slots that are still
+    // "empty", so a batch that changes form between evaluations (compact pattern across the cache threshold) refills them
+    if (a.fused && partial_dirty_) {
+        check(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(d_partial_), kEmptySlotWord, 4 * (size_t)partial_cap_, stream),
+              "hipMemsetD32Async(partial)");
+        partial_dirty_ = false;
+    }
+    if (!a.fused && needF) partial_dirty_ = true;
     a.obj = dObj;
     a.done = done; a.done_seq = done_seq;
     a.waves_per_cu = waves_forced_ ? waves_per_cu_ : lp.waves_per_cu;

@@ -100,6 +100,7 @@ private:
     int tile_nodes_forced_ = 0;         // TOLFG_TILE_NODES (measurements)
     int fused_forced_ = -1;             // TOLFG_FUSED=0/1 overrides one launch vs fg_kernel + finalize_kernel (measurements)
     int nt_forced_ = -1;                // TOLFG_NT_STORES=0/1 overrides the size-based choice (measurements)
+    bool partial_dirty_ = false;        // the partial slots hold a two-launch evaluation's sums (not "empty")
     int tail_forced_ = -1, tail_nt_forced_ = 0;   // TOLFG_TAIL=count:nt overrides the finer-tiled tail (measurements)
     int xcd_forced_ = -1;               // TOLFG_XCD=0/1 overrides the tile order (measurements)
     int ntraj_ = 0, cap_ = 0;
