@@ -1,0 +1,57 @@
+"""The single-launch form (the last-arriving tile wave finalizes: arrival counters, polled partial slots) against the
+two-launch form (finalize_kernel) on random shapes, twice per shape on the same objects -- the concurrency-sensitive part
+of the batched path.  Defects, boundary rows and the Jacobian must be bitwise equal; the objective sums the same partials
+in the same order in both forms, so it must be bitwise equal too."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+AIRCRAFT = ["tempest", "skywalker", "tempest_eric", "tempest_wences", "tempest_will"]
+
+
+def same(a, b):
+    """Bitwise equality where NaN equals NaN (the pad elements of a mixed batch's rows keep the fill value)."""
+    return bool(((a == b) | (torch_isnan(a) & torch_isnan(b))).all())
+
+
+def torch_isnan(t):
+    return t != t
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_single_launch_equals_two_launch_on_random_shapes(tolfg, monkeypatch, seed):
+    import torch
+    rng = np.random.default_rng(900 + seed)
+    for case in range(6):
+        mission = ("S10", "G7", "mixed")[int(rng.integers(3))]
+        N = int(rng.choice([1, 3, 17, 52, 53, 64, 65, 100, 128, 200, 257]))
+        B = int(rng.choice([1, 2, 9, 10, 33, 127, 600, 1500]))
+        dtype = ("f64", "f32")[int(rng.integers(2))]
+        pattern = ("reference", "compact")[int(rng.integers(2))]
+        trajs = [tolfg.Trajectory(aircraft=t % 5, mission=("S10", "G7")[t % 2] if mission == "mixed" else mission,
+                                  radius_goal=100.0 if (mission == "S10" or (mission == "mixed" and t % 2 == 0)) else 0.0,
+                                  Vref=1.0 + 0.01 * (t % 97), xi=float(t % 7), zi=-30.0 - (t % 11)) for t in range(B)]
+        outs = []
+        for fused in ("1", "0"):
+            monkeypatch.setenv("TOLFG_FUSED", fused)
+            monkeypatch.setenv("TOLFG_NO_SINGLE_LAUNCH", "1")        # small batches through the tile-per-workgroup kernels too
+            bt = tolfg.Batch(mission, AIRCRAFT, ts=N, dtype=dtype, pattern=pattern)
+            bt.set_trajectories(trajs)
+            dX, dF, dG = bt.alloc(B)
+            bt.x0_device(dX)
+            gen = torch.Generator(device="cuda").manual_seed(int(1000 * seed + case))
+            dX[:, 1:bt.n] += (0.01 * torch.randn(B, bt.n - 1, dtype=torch.float64, device="cuda", generator=gen)).to(dX.dtype)
+            res = []
+            for rep in range(2):                                     # the second evaluation finds the counters and slots as the first left them
+                dF.fill_(float("nan")); dG.fill_(float("nan"))
+                bt.eval(dX, dF, dG)
+                torch.cuda.synchronize()
+                res.append((dF[:, :bt.neF].clone(), dG[:, :bt.neG].clone()))
+            assert same(res[0][0], res[1][0]) and same(res[0][1], res[1][1]), (mission, N, B, dtype, pattern, fused)
+            assert torch.isfinite(res[0][0][:, :bt.neF - 1]).all()    # (a mixed batch pads its S10 rows by one element)
+            outs.append(res[0])
+            bt.close()
+        what = (mission, N, B, dtype, pattern)
+        assert same(outs[0][1], outs[1][1]), what
+        assert same(outs[0][0], outs[1][0]), what
