@@ -242,11 +242,11 @@ int  tolfg_batch_eval(tolfg_batch *b, int B,
  * RCCL all-gather across GPUs (a separate small kernel; tolfg_batch_eval's dObj does it for free). */
 int  tolfg_batch_objectives(tolfg_batch *b, int B, const void *dF, long ldf, void *dObj, void *stream);
 
-/* Measurement aid for bench.py's roofline line.  While enabled, every tolfg_batch_eval records a
- * pair of HIP events on the launch stream immediately around fg_kernel (the dominant kernel; the
- * small finalize kernel that follows is outside the pair).  tolfg_batch_kernel_time waits for the
- * recorded launches, returns how many there were and their average / minimum duration in ms, and
- * resets the record. */
+/* Measurement aid.  While enabled, every tolfg_batch_eval attaches a start and a stop HIP event to its dispatches
+ * (hipExtLaunchKernelGGL): around the whole evaluation -- fg_kernel alone in the single-launch form, fg_kernel through
+ * finalize_kernel in the two-launch form.  tolfg_batch_kernel_time waits for the recorded launches, returns how many
+ * there were and their average / minimum duration in ms, and resets the record.  Dispatch profiling is not free: every
+ * launch takes 4-16 us longer while it is on (profiles/r02_event_cost.md), so bench.py keeps it out of its timed region. */
 int  tolfg_batch_set_timing(tolfg_batch *b, int enable);
 int  tolfg_batch_kernel_time(tolfg_batch *b, double *avg_ms, double *min_ms);
 
