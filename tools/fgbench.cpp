@@ -32,6 +32,7 @@ struct Shape {
     int c0;
 };
 
+static long g_ldg_pad = 0;          // ldgpad=: extra elements between the rows of G (row-stride experiments)
 Shape make_shape(int B, int N, int mission, int dtype)
 {
     Shape s{};
@@ -42,7 +43,7 @@ Shape make_shape(int B, int N, int mission, int dtype)
     s.c0 = mission == tolfg::MISSION_S10 ? 3 * N + 4 : N + 6;
     const long v = dtype == 0 ? 2 : 4;
     auto up = [&](long m) { return (m + v - 1) / v * v; };
-    s.ldx = up(s.n); s.ldf = up(s.neF); s.ldg = up(s.neG);
+    s.ldx = up(s.n); s.ldf = up(s.neF); s.ldg = up(s.neG) + g_ldg_pad;
     return s;
 }
 
@@ -191,6 +192,7 @@ int main(int argc, char **argv)
         if (!strncmp(argv[i], "nt=", 3)) { bf.nt = atoi(argv[i] + 3); continue; }
         if (!strncmp(argv[i], "xcd=", 4)) { bf.xcd = atoi(argv[i] + 4); continue; }
         if (!strncmp(argv[i], "xcdpct=", 7)) { bf.xcdpct = atoi(argv[i] + 7); continue; }       // share of the tiles dealt XCD-contiguously
+        if (!strncmp(argv[i], "ldgpad=", 7)) { g_ldg_pad = atol(argv[i] + 7); bf.release(); bf.sh = Shape{}; continue; }
         if (!strncmp(argv[i], "tail=", 5)) { bf.tail_count = atoi(argv[i] + 5); const char *c = strchr(argv[i], ':'); if (c) bf.tail_nt = atoi(c + 1); continue; }   // tail=count:nt
         if (!strncmp(argv[i], "persist=", 8)) { bf.persist = atoi(argv[i] + 8); continue; }     // workgroups per CU, 0 = off
         if (!strncmp(argv[i], "pat=", 4)) { bf.pat = atoi(argv[i] + 4); bf.release(); bf.sh = Shape{}; continue; }
