@@ -257,8 +257,8 @@ def config_records(tol_amd, torch, device):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--batch", type=int, default=4096, help="trajectories per GPU (weak scaling)")
     ap.add_argument("--global-batch", type=int, default=0,
                     help="total trajectories over all GPUs (strong scaling; configs[3]: 1024, configs[4]: 8192 with --mission mixed)")
