@@ -298,3 +298,32 @@ def test_batched_need_flags_and_repeated_launches(tolfg, oracle, mission):
         bt.eval(dX, dF, dG)
     torch.cuda.synchronize()
     assert torch.equal(dF[:, :bt.neF], F0[:, :bt.neF]) and torch.equal(dG[:, :bt.neG], G0[:, :bt.neG])   # pad columns hold NaN
+
+
+@pytest.mark.parametrize("mission,N", [("S10", 200), ("G7", 64), ("S10", 33)])
+def test_callback_with_the_callers_own_arrays_kept_across_calls(tolfg, oracle, mission, N):
+    """snOptA hands DEFINEGusrfg_ the SAME x, F and G arrays call after call.  The library registers an array it sees
+    twice and lets the kernel read x from it and write F and G into it (no staging copies); x changes in place between
+    calls.  Every call must return the right numbers (ts = 33: n is odd, x then still goes through the pinned copy)."""
+    import ctypes as C
+    p = tolfg.Problem(mission, "skywalker", ts=N, radius_goal=100.0 if mission == "S10" else 0.0)
+    o = oracle.Problem(mission, "skywalker", N=N, radius_goal=100.0 if mission == "S10" else 0.0)
+    lib = tolfg.lib()
+    x = np.ascontiguousarray(o.x0(), dtype=np.float64)
+    F, G = np.full(p.neF, np.nan), np.full(p.neG, np.nan)
+    dbl = C.POINTER(C.c_double)
+    st, n, neF, neG = C.c_int(1), C.c_int(p.n), C.c_int(p.neF), C.c_int(p.neG)
+    one, zero = C.c_int(1), C.c_int(0)
+    rng = np.random.default_rng(3)
+    p.make_current()
+    for call in range(6):
+        x += 0.003 * rng.uniform(-1, 1, x.shape) * (1 + np.abs(x))          # in place: same array, new values
+        x[0] = abs(x[0]) + 0.01
+        F[:] = np.nan; G[:] = np.nan
+        lib.DEFINEGusrfg_(C.byref(st), C.byref(n), x.ctypes.data_as(dbl), C.byref(one), C.byref(neF), F.ctypes.data_as(dbl), C.byref(one),
+                          C.byref(neG), G.ctypes.data_as(dbl), None, C.byref(zero), None, C.byref(zero), None, C.byref(zero))
+        assert st.value == 1
+        Fo, Go = o.eval(x)
+        assert_close(F, Fo, what=f"call {call} F")
+        assert_close(G, np.where(o.undefined_mask(), 0.0, Go), mask=o.undefined_mask(), what=f"call {call} G")
+    p.close()

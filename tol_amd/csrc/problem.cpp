@@ -525,11 +525,19 @@ void *problem::device_view(void *p, size_t bytes)
     return nullptr;
 }
 
-void problem::stage_and_launch(const double xin[], bool needF, bool needG, double *Fuser, double *Guser)
+void problem::stage_and_launch(const double xin[], bool needF, bool needG, double *Fuser, double *Guser, bool caller_keeps_x)
 {
     ensure_device();
     check(hipSetDevice(eng_->device()), "hipSetDevice");
-    std::memcpy(hx_, xin, sizeof(double) * n);
+    // x: the callback's caller keeps its array untouched until we return, so an array seen twice (SNOPT's own x) is
+    // registered like F and G and read by the kernel where it lies; otherwise, and always for the separate
+    // modelWind / computeF / computeG entry points (they compare against the copy), x goes through the pinned copy
+    const bool direct = zero_copy_ && sizeof(double) * ((size_t)n + neF + neG) <= zero_copy_limit_;
+    // (the window loads are 16 bytes wide and may touch element n of a row: only an x of even length is read in place)
+    static const bool copy_x = std::getenv("TOLFG_CALLBACK_COPY_X") != nullptr;       // measurement: always stage x
+    const void *vX = (caller_keeps_x && direct && ldx_ == n && !copy_x) ? device_view(const_cast<double *>(xin), sizeof(double) * n) : nullptr;
+    if (!vX) std::memcpy(hx_, xin, sizeof(double) * n);
+    x_copied_ = vX == nullptr;
     void *vF = (needF && Fuser) ? device_view(Fuser, sizeof(double) * neF) : nullptr;
     void *vG = (needG && Guser) ? device_view(Guser, sizeof(double) * neG) : nullptr;
     landF_ = vF ? Fuser : hF_;
@@ -538,7 +546,6 @@ void problem::stage_and_launch(const double xin[], bool needF, bool needG, doubl
     // follows them, so nothing is copied or synchronised (measured per call, profiles/r02_callback.md:
     // ts=200 22.6 vs 33.6 us staged; ts=2000 52 vs 86 us).  Only problems beyond zero_copy_limit_
     // (64 MB of x+F+G, ts > ~60000) keep device buffers and DMA copies.
-    const bool direct = zero_copy_ && sizeof(double) * ((size_t)n + neF + neG) <= zero_copy_limit_;
     flagged_ = false;
     if (direct) {
         // One trajectory is ~200 KB: launch + PCIe latency dominate, not bandwidth.  The kernel reads
@@ -546,7 +553,7 @@ void problem::stage_and_launch(const double xin[], bool needF, bool needG, doubl
         // pinned staging buffers, then reports through the completion word: no copy commands, no
         // stream synchronisation.
         flagged_ = use_flag_;
-        eng_->eval(1, hx_, ldx_, vF ? vF : hF_, ldf_, vG ? vG : hG_, ldg_, dW_, needF, needG, stream_, nullptr,
+        eng_->eval(1, vX ? vX : hx_, ldx_, vF ? vF : hF_, ldf_, vG ? vG : hG_, ldg_, dW_, needF, needG, stream_, nullptr,
                    flagged_ ? done_ : nullptr, flagged_ ? ++seq_ : 0);
     } else {
         check(hipMemcpyAsync(dX_, hx_, sizeof(double) * n, hipMemcpyHostToDevice, stream_), "H2D x");
@@ -657,7 +664,7 @@ void problem::evaluate(const double xin[], bool needF, double F[], bool needG, d
     if (trace) {
         using clk = std::chrono::steady_clock;
         const auto t0 = clk::now();
-        stage_and_launch(xin, needF, needG, F, G);
+        stage_and_launch(xin, needF, needG, F, G, true);
         const auto t1 = clk::now();
         if (!chunked_) wait_done();
         else check(hipStreamSynchronize(stream_), "stream sync");
@@ -670,7 +677,7 @@ void problem::evaluate(const double xin[], bool needF, double F[], bool needG, d
         if (debug && needG) dump("Goutput.txt", G, neG);
         return;
     }
-    stage_and_launch(xin, needF, needG, F, G);
+    stage_and_launch(xin, needF, needG, F, G, true);
     collect(needF, F, needG, G);
     if (debug && needF) dump("Foutput.txt", F, neF);
     if (debug && needG) dump("Goutput.txt", G, neG);
@@ -683,13 +690,13 @@ void problem::modelWind(const double xin[])
 
 void problem::computeF(const double xin[], double F[])
 {
-    if (!staged_ || !haveF_ || std::memcmp(hx_, xin, sizeof(double) * n) != 0) stage_and_launch(xin, true, false);
+    if (!staged_ || !x_copied_ || !haveF_ || std::memcmp(hx_, xin, sizeof(double) * n) != 0) stage_and_launch(xin, true, false);
     collect(true, F, false, nullptr);
 }
 
 void problem::computeG(const double xin[], double G[])
 {
-    if (!staged_ || !haveG_ || std::memcmp(hx_, xin, sizeof(double) * n) != 0) stage_and_launch(xin, false, true);
+    if (!staged_ || !x_copied_ || !haveG_ || std::memcmp(hx_, xin, sizeof(double) * n) != 0) stage_and_launch(xin, false, true);
     collect(false, nullptr, true, G);
 }
 

@@ -161,7 +161,8 @@ protected:
 private:
     void ensure_device();
     // Fuser / Guser: the caller's arrays when known at launch time (DEFINEGusrfg_), else nullptr
-    void stage_and_launch(const double x[], bool needF, bool needG, double *Fuser = nullptr, double *Guser = nullptr);
+    void stage_and_launch(const double xin[], bool needF, bool needG, double *Fuser = nullptr, double *Guser = nullptr,
+                          bool caller_keeps_x = false);
     void collect(bool wantF, double F[], bool wantG, double G[]);
     void wait_done();
     // device address of a caller-owned host array, registered on first sight (SNOPT hands the same F and
@@ -188,6 +189,7 @@ private:
     double *dX_ = nullptr, *dF_ = nullptr, *dG_ = nullptr, *dW_ = nullptr;
     long ldx_, ldf_, ldg_;
     bool device_ready_ = false, staged_ = false, haveF_ = false, haveG_ = false;
+    bool x_copied_ = true;              // hx_ holds the x of the staged evaluation (false: the kernel read the caller's own array)
     size_t zero_copy_limit_ = 64u << 20;    // bytes of x+F+G up to which the kernels address host memory directly
     bool zero_copy_ = true;           // TOLFG_CALLBACK_STAGING=1 selects explicit H2D/D2H copies instead
 };
