@@ -32,6 +32,7 @@ struct Shape {
     int c0;
 };
 
+static long g_goff = 0;             // goff=: G starts this many elements into its allocation (alignment experiments)
 static long g_ldg_pad = 0;          // ldgpad=: extra elements between the rows of G (row-stride experiments)
 Shape make_shape(int B, int N, int mission, int dtype)
 {
@@ -104,9 +105,9 @@ void fill(Buffers &bf, const Shape &sh, int xbuf)
         tr[b].mission = sh.mission == tolfg::MISSION_MIXED ? (b & 1) : sh.mission;
     }
     CK(hipMalloc(&bf.dF, bf.es() * sh.B * sh.ldf));
-    CK(hipMalloc(&bf.dG, bf.es() * sh.B * sh.ldg));
+    CK(hipMalloc(&bf.dG, bf.es() * (sh.B * sh.ldg + 64)));
     CK(hipMalloc(&bf.dF2, bf.es() * sh.B * sh.ldf));
-    CK(hipMalloc(&bf.dG2, bf.es() * sh.B * sh.ldg));
+    CK(hipMalloc(&bf.dG2, bf.es() * (sh.B * sh.ldg + 64)));
     CK(hipMemset(bf.dF2, 0xff, bf.es() * sh.B * sh.ldf));      // rows of a mixed batch leave their tails untouched
     CK(hipMemset(bf.dG2, 0xff, bf.es() * sh.B * sh.ldg));
     CK(hipMalloc(&bf.dT, sizeof(tolfg::TrajDev) * sh.B));
@@ -121,7 +122,7 @@ tolfg::FgArgs make_args(Buffers &bf, int max_nt, int cap, int fused, int xi, voi
 {
     const Shape &sh = bf.sh;
     tolfg::FgArgs a{};
-    a.X = bf.dX[xi % bf.dX.size()]; a.ldx = sh.ldx; a.F = F; a.ldf = sh.ldf; a.G = G; a.ldg = sh.ldg;
+    a.X = bf.dX[xi % bf.dX.size()]; a.ldx = sh.ldx; a.F = F; a.ldf = sh.ldf; a.G = static_cast<char *>(G) + g_goff * (sh.dtype == 0 ? 8 : 4); a.ldg = sh.ldg;
     a.wind = nullptr; a.traj = bf.dT; a.B = sh.B; a.N = sh.N; a.c0[0] = 3 * sh.N + 4; a.c0[1] = sh.N + 6;
     tolfg::plan_tiles(sh.N, sh.dtype, max_nt, &a.tiles, &a.nt);
     if (bf.tail_count > 0 && !bf.persist) {                 // finer tiles for the trajectories reached last
@@ -192,6 +193,7 @@ int main(int argc, char **argv)
         if (!strncmp(argv[i], "nt=", 3)) { bf.nt = atoi(argv[i] + 3); continue; }
         if (!strncmp(argv[i], "xcd=", 4)) { bf.xcd = atoi(argv[i] + 4); continue; }
         if (!strncmp(argv[i], "xcdpct=", 7)) { bf.xcdpct = atoi(argv[i] + 7); continue; }       // share of the tiles dealt XCD-contiguously
+        if (!strncmp(argv[i], "goff=", 5)) { g_goff = atol(argv[i] + 5); bf.release(); bf.sh = Shape{}; continue; }
         if (!strncmp(argv[i], "ldgpad=", 7)) { g_ldg_pad = atol(argv[i] + 7); bf.release(); bf.sh = Shape{}; continue; }
         if (!strncmp(argv[i], "tail=", 5)) { bf.tail_count = atoi(argv[i] + 5); const char *c = strchr(argv[i], ':'); if (c) bf.tail_nt = atoi(c + 1); continue; }   // tail=count:nt
         if (!strncmp(argv[i], "persist=", 8)) { bf.persist = atoi(argv[i] + 8); continue; }     // workgroups per CU, 0 = off
