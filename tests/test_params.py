@@ -136,3 +136,64 @@ def test_reference_reader_on_a_nasty_file(tmp_path, oracle):
     mine = mine.copy()
     mine[[8, 11, 12]] = mine[[8, 11, 12]] * np.pi / 180.0
     assert np.array_equal(out, mine)
+
+
+_TOKENS = ["1", "-2.5e3", "+.5", "1.", "0x1p3", "0x10", "inf", "-inf", "nan", "1e999", "-1e-999", " 3", "\t4", "5abc", "6/7", "7 // c", "8\\n", "9\r",
+           "", "abc", "/ 5", "--1", "1e", "1e+", ".", "-", "+", "0x", "1_000", "1,5", "  ", "// 3", "3 4", "1e5e5", ".e1", "00012", "1d3", "infinity x",
+           "nanx", "-0", "1e-320", "\r", "12 / 13 / 14", "\\n", "0.1e+2/"]
+
+
+def _random_file(rng, n_lines):
+    return "\n".join(_TOKENS[int(i)] for i in rng.integers(0, len(_TOKENS), n_lines)) + "\n"
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_readers_agree_on_random_line_soups(tmp_path, oracle, tolfg, seed):
+    """Seeded random files over a vocabulary of well- and ill-formed lines: the product's reader and the oracle's keep and drop the
+    same lines and read the same values, and -- where oracle/_ref exists (build container) -- so does the reference's own reader
+    (compiled in place from src/parameters.cpp:14-34): a file that yields exactly 15 values must give the reference's aircraft
+    constructor the same 15 numbers, any other count must make it throw (src/parameters.cpp:45-67)."""
+    rng = np.random.default_rng(4400 + seed)
+    R = None
+    if os.path.exists(REFSO):
+        R = C.CDLL(REFSO)
+        R.ref_aircraft.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_double)]
+        R.ref_aircraft.restype = C.c_int
+    (tmp_path / "aircraft").mkdir()
+    hits = 0
+    for k in range(60):
+        text = _random_file(rng, int(rng.integers(10, 40)))
+        f = tmp_path / "aircraft" / f"soup{k}.param"
+        f.write_bytes(text.encode())
+        vo, co = oracle.read_params(str(f))
+        vp, cp = product_read(tolfg, str(f))
+        assert co == cp, (seed, k, text)
+        assert np.array_equal(vo, vp, equal_nan=True), (seed, k, text)
+        if R is not None:
+            out = np.zeros(15)
+            rc = R.ref_aircraft(f"soup{k}".encode(), (str(tmp_path) + "/").encode(), out.ctypes.data_as(C.POINTER(C.c_double)))
+            if co == 15:
+                hits += 1
+                want = vo.copy()
+                want[[8, 11, 12]] = want[[8, 11, 12]] * np.pi / 180.0
+                assert rc == 0 and np.array_equal(out, want, equal_nan=True), (seed, k, text)
+            else:
+                assert rc == -1, (seed, k, co, text)
+    # a count of exactly 15 is rare in a random soup, so also grow files line by line until they hold exactly 15 values
+    for k in range(12):
+        lines = []
+        while True:
+            lines.append(_TOKENS[int(rng.integers(0, len(_TOKENS)))])
+            f = tmp_path / "aircraft" / f"grown{k}.param"
+            f.write_bytes(("\n".join(lines) + "\n").encode())
+            vo, co = oracle.read_params(str(f))
+            if co >= 15:
+                break
+        vp, cp = product_read(tolfg, str(f))
+        assert co == cp == 15 and np.array_equal(vo, vp, equal_nan=True), (seed, k, lines)
+        if R is not None:
+            out = np.zeros(15)
+            assert R.ref_aircraft(f"grown{k}".encode(), (str(tmp_path) + "/").encode(), out.ctypes.data_as(C.POINTER(C.c_double))) == 0, (seed, k, lines)
+            want = vo.copy()
+            want[[8, 11, 12]] = want[[8, 11, 12]] * np.pi / 180.0
+            assert np.array_equal(out, want, equal_nan=True), (seed, k, lines)
