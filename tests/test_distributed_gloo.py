@@ -34,10 +34,12 @@ def _worker(rank, world, port, total, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from tol_amd.distributed import gather_objectives, shard_bounds
+    from tol_amd.distributed import gather_objectives, mean_objective, shard_bounds
     lo, hi = shard_bounds(total, rank, world)
     local = torch.tensor([_objective(t) for t in range(lo, hi)], dtype=torch.float64)
     full = gather_objectives(local, total)
+    mean = mean_objective(local, total)                       # the optional all-reduce(sum) of SURVEY section 8e
+    assert abs(mean.item() - full.mean().item()) <= 1e-12 * abs(full.mean().item())
     trim, work = gather_objectives(local, total, async_op=True)
     work.wait()
     assert torch.equal(trim(), full)

@@ -45,3 +45,12 @@ def gather_objectives(local_obj, total, group=None, async_op=False):
     if async_op:
         return trim, work
     return trim()
+
+
+def mean_objective(local_obj, total, group=None):
+    """Monte-Carlo mean of the objectives over all `total` trajectories of the job: one all-reduce(sum) of each rank's
+    partial sum (the optional second collective; latency-bound, 8 bytes per rank)."""
+    s = local_obj.sum(dtype=torch.float64).reshape(1)
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(s, op=dist.ReduceOp.SUM, group=group)
+    return s / float(total)
