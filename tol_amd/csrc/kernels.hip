@@ -59,6 +59,8 @@ constexpr double kTwoPi = 6.283185307179586476925286766559;
 
 // LDS row of one node (elements): 32 computed Jacobian values and the 3 constants (slab_table.h).
 constexpr int RS = 35;             // odd stride: conflict-free ds_write_b64 across lanes
+// a wave's LDS region in the one-workgroup-per-trajectory kernel: a spare row + 64 rows, whole 16-byte vectors
+constexpr int WAVE_LDS = ((TILE + 1) * RS + 3) & ~3;
 // an empty objective-partial slot of the polling fused path: a NaN no arithmetic produces, both halves
 // equal so that hipMemsetD32 can write it
 constexpr unsigned long long kEmptySlot = 0xFFFBADADFFFBADADull;
@@ -314,117 +316,126 @@ template <typename T, int WIND> struct NodeCtx {
     }
 };
 
-// Stream the tile's cnt slabs (SLABN*cnt contiguous elements at gslab) out of the LDS rows.
-// Wave instruction i covers elements [64*GV*i, 64*GV*(i+1)); the (node, element) a lane meets
-// repeats every P instructions (13 for the 104-entry slab, 23 for the 46-entry one), so the P LDS
-// offsets are formed once, packed two per register.
-template <int PAT, int GV> struct SlabGeom {
+// ---- the slab stream.  A tile's slabs are SLABN*cnt contiguous elements of G (gslab); the wave writes them as
+// whole, 16-byte aligned vectors of GV elements, 1 KiB per wave instruction, wherever the region sits relative to
+// a 16-byte boundary: with the region starting SHIFT elements past a boundary the stream is cut SHIFT elements
+// earlier, i.e. vector q covers stream elements [q*GV - SHIFT, q*GV - SHIFT + GV); the few elements before the
+// first and after the last whole vector leave as scalars.  Round R of the wave handles vectors 64*R + lane.
+// Which LDS slot feeds stream element r = SLABN*node + e is slab_table.h's code(e); the (node, element) pairs a
+// lane meets repeat every P rounds (NPP nodes later), so the byte offsets of a lane's P*GV elements -- relative
+// to the LDS row of the period's first node, rows laid out one RS-element row per node after one spare row
+// (SHIFT > 0 reaches into the node before) -- are a compile-time table per (element size, pattern, SHIFT),
+// 16 bits each, which every wave loads with a few coalesced 16-byte loads.  (Round 2 formed these offsets with
+// integer arithmetic and byte loads per wave: ~10 VALU instructions per element, 40 % of the fp32 kernel's
+// dynamic VALU work.)
+template <int ES, int PAT> struct StreamGeom {
     static constexpr int SLABN = PAT == PATTERN_COMPACT ? SLAB_COMPACT : SLAB_FULL;
-    static constexpr int PN = SLABN / GV;                      // vectors per node
-    static constexpr int NPER = gcd_c(PN, TILE);               // periods per 64-node tile
-    static constexpr int P = PN / NPER;                        // wave instructions per period
-    static constexpr int NPP = TILE / NPER;                    // nodes per period
-    static_assert(SLABN % GV == 0, "slab must be a whole number of vectors");
+    static constexpr int GV = 16 / ES;                                     // elements per 16-byte vector
+    static constexpr int P = SLABN / gcd_c(SLABN, TILE * GV);              // rounds per period
+    static constexpr int NPP = TILE * GV * P / SLABN;                      // nodes per period
+    static constexpr int D = (P * GV + 1) / 2;                             // dwords per lane (two offsets each)
+    static constexpr int CH = (D + 3) / 4;                                 // 16-byte chunks per lane
+    static_assert((SLABN * 4) % GV == 0, "a tile starts at a node number that is a multiple of 4");
 };
 
-// SHIFT: the slab region starts SHIFT elements past a 16-byte boundary (c0 odd, or c0 % 4 == 2 in fp32).
-// The stream is then cut SHIFT elements earlier: vector q covers elements [q*GV - SHIFT, q*GV - SHIFT + GV),
-// every vector 1 <= q < total is whole and aligned, and the first GV - SHIFT and the last SHIFT elements
-// leave as scalars.  A vector may then straddle two nodes, so each element carries its own node.
-template <typename T, int PAT, int GV, int SHIFT> struct SlabOffsets {
-    typedef SlabGeom<PAT, GV> Gm;
-    unsigned pk[Gm::P][(GV + 1) / 2];
-    __device__ __forceinline__ static int code(int e)
-    {
-        if constexpr (PAT == PATTERN_COMPACT) return kSlabCompact.c[e];
-        else return kSlabFull.c[e];
-    }
-    // LDS offset of stream element r of a period, relative to the row of the node BEFORE the period's
-    // first one when SHIFT > 0 (r may be negative then), else relative to the period's first row
-    __device__ __forceinline__ static unsigned elem(int r)
-    {
-        if constexpr (SHIFT == 0) {
-            const int nd = r / Gm::SLABN;
-            return (unsigned)(nd * RS + code(r - nd * Gm::SLABN));
-        } else {
-            const int nd = (r + Gm::SLABN) / Gm::SLABN;          // = floor(r / SLABN) + 1 for r >= -SLABN
-            return (unsigned)(nd * RS + code(r + Gm::SLABN - nd * Gm::SLABN));
-        }
-    }
-    __device__ __forceinline__ void init(int lane)
-    {
-#pragma unroll
-        for (int t = 0; t < Gm::P; t++) {
-            const int r0 = (TILE * t + lane) * GV - SHIFT;
-#pragma unroll
-            for (int h = 0; h < (GV + 1) / 2; h++) {
-                const unsigned lo = elem(r0 + 2 * h);
-                const unsigned hi = (2 * h + 1 < GV) ? elem(r0 + 2 * h + 1) : 0u;
-                pk[t][h] = lo | (hi << 16);
-            }
-        }
-    }
-    __device__ __forceinline__ int off(int t, int v) const
-    {
-        const unsigned w = pk[t][v >> 1];
-        return (v & 1) ? (int)(w >> 16) : (int)(w & 0xffffu);
-    }
+template <int ES, int PAT> struct StreamTable {
+    typedef StreamGeom<ES, PAT> Gm;
+    unsigned w[Gm::GV][Gm::CH][TILE][4];      // [SHIFT][chunk][lane][dword]: coalesced 16-byte loads
 };
 
-template <typename T, int PAT, int GV, bool NT, int SHIFT>
-__device__ __forceinline__ void store_slabs(const T *lds, T *gslab, int cnt, int lane)
+template <int PAT> __device__ __forceinline__ int slab_code_dev(int e)
 {
+    if constexpr (PAT == PATTERN_COMPACT) return kSlabCompact.c[e];
+    else return kSlabFull.c[e];
+}
+
+constexpr int slab_code(int pat, int e)
+{
+    return pat == PATTERN_COMPACT ? make_compact_table().c[e] : make_slab_table().c[e];
+}
+
+template <int ES, int PAT> constexpr StreamTable<ES, PAT> make_stream_table()
+{
+    typedef StreamGeom<ES, PAT> Gm;
+    StreamTable<ES, PAT> t{};
+    unsigned char code[Gm::SLABN] = {};
+    for (int e = 0; e < Gm::SLABN; e++) code[e] = (unsigned char)slab_code(PAT, e);
+    for (int sh = 0; sh < Gm::GV; sh++)
+        for (int lane = 0; lane < TILE; lane++)
+            for (int i = 0; i < Gm::P * Gm::GV; i++) {
+                const int r = (TILE * (i / Gm::GV) + lane) * Gm::GV - sh + (i % Gm::GV);   // >= -sh
+                const int nd = (r + Gm::SLABN) / Gm::SLABN;                // row index incl. the spare row: floor(r/SLABN) + 1
+                const int e = r + Gm::SLABN - nd * Gm::SLABN;
+                const unsigned off = (unsigned)((nd * RS + code[e]) * ES);
+                const int d = i / 2;
+                t.w[sh][d / 4][lane][d % 4] |= (i & 1) ? (off << 16) : off;
+            }
+    return t;
+}
+
+template <int ES, int PAT> __device__ constexpr StreamTable<ES, PAT> kStream = make_stream_table<ES, PAT>();
+
+// TN = nodes a tile may hold (64, or 128 with two nodes per lane): bounds the unrolled rounds.
+// load() asks for the lane's offsets -- early, together with the x window, so that they are back long before the
+// stream starts and no wait for them ends up behind the wave's own defect stores (one in-order vmcnt);
+// run() streams the rows out.
+template <typename T, int PAT, bool NT, int TN> struct SlabStream {
+    static constexpr int ES = (int)sizeof(T);
+    typedef StreamGeom<ES, PAT> Gm;
+    static constexpr int GV = Gm::GV, SLABN = Gm::SLABN, P = Gm::P;
     typedef typename Vec<T, GV>::type vec;
-    typedef SlabGeom<PAT, GV> Gm;
-    SlabOffsets<T, PAT, GV, SHIFT> so;
-    so.init(lane);
-    const int total = Gm::PN * cnt;
-#pragma unroll 1
-    for (int j = 0; j < Gm::NPER; j++) {
-        if (j * Gm::NPP >= cnt) break;   // wave-uniform
-        const T *grp = lds + (j * Gm::NPP - (SHIFT ? 1 : 0)) * RS;
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    static constexpr int RMAX = (TN * SLABN + GV - 1) / (TILE * GV) + 1;   // rounds a full tile needs at most
+    static constexpr int PU = P < RMAX ? P : RMAX;                         // table rounds actually used
+    static constexpr int CHU = ((PU * GV + 1) / 2 + 3) / 4;
+    u4 tb[CHU];
+    T *gslab;
+    int shift;             // the region starts `shift` elements past a 16-byte boundary: wave-uniform
+
+    __device__ __forceinline__ void load(T *gslab_, int lane)
+    {
+        gslab = gslab_;
+        shift = __builtin_amdgcn_readfirstlane((int)((reinterpret_cast<unsigned long long>(gslab_) / ES) % GV));
+        const u4 *tp = reinterpret_cast<const u4 *>(&kStream<ES, PAT>.w[0][0][0][0]) + (long)shift * (Gm::CH * TILE) + lane;
 #pragma unroll
-        for (int t = 0; t < Gm::P; t++) {
-            const int p = TILE * (Gm::P * j + t) + lane;
-            if (p < total && (SHIFT == 0 || p >= 1)) {
-                if constexpr (GV == 1) {
-                    stream_store<NT>(gslab + p, grp[so.off(t, 0)]);
-                } else {
-                    vec val;
+        for (int c = 0; c < CHU; c++) tb[c] = tp[c * TILE];
+    }
+
+    __device__ __forceinline__ void run(const T *lds, int cnt, int lane) const
+    {
+        const int E = SLABN * cnt;                         // elements of the region
+        const int qhi = (E + shift) / GV;                  // whole vectors are q in [shift ? 1 : 0, qhi)
+        const char *lb = reinterpret_cast<const char *>(lds);
+        vec *gp = reinterpret_cast<vec *>(gslab - shift) + lane;
 #pragma unroll
-                    for (int v = 0; v < GV; v++) val[v] = grp[so.off(t, v)];
-                    stream_store<NT>(reinterpret_cast<vec *>(gslab + (long)p * GV - SHIFT), val);
+        for (int R = 0; R < RMAX; R++) {
+            if (TILE * R >= qhi) break;                    // wave-uniform
+            const int j = R / P, t = R % P;
+            const char *grp = lb + j * Gm::NPP * RS * ES;
+            const int q = TILE * R + lane;
+            const bool whole = R > 0 && TILE * (R + 1) <= qhi;     // wave-uniform: no lane is cut off
+            if (whole || (q < qhi && (R > 0 || shift == 0 || lane > 0))) {
+                vec val;
+#pragma unroll
+                for (int v = 0; v < GV; v++) {
+                    const int i = t * GV + v;
+                    const unsigned wv = tb[(i / 2) / 4][(i / 2) % 4];
+                    const unsigned off = (i & 1) ? (wv >> 16) : (wv & 0xffffu);
+                    val[v] = *reinterpret_cast<const T *>(grp + off);
                 }
+                stream_store<NT>(gp + TILE * R, val);
             }
         }
-    }
-    if constexpr (SHIFT > 0) {
-        // head: elements [0, GV - SHIFT) of the first node; tail: the last SHIFT elements of the last node
-        if (lane < GV - SHIFT) gslab[lane] = lds[SlabOffsets<T, PAT, GV, 0>::code(lane)];
-        else if (lane < GV) {
-            const int e = Gm::SLABN - GV + lane;           // SLABN - SHIFT + (lane - (GV - SHIFT))
-            gslab[(long)Gm::SLABN * (cnt - 1) + e] = lds[(cnt - 1) * RS + SlabOffsets<T, PAT, GV, 0>::code(e)];
+        // the elements before the first and after the last whole vector
+        const int ntail = E + shift - qhi * GV;            // in [0, GV)
+        if (shift > 0 && lane < GV - shift) {
+            gslab[lane] = lds[RS + slab_code_dev<PAT>(lane)];
+        } else if (lane >= GV && lane < GV + ntail) {
+            const int e = qhi * GV - shift + (lane - GV) - SLABN * (cnt - 1);
+            gslab[(long)SLABN * (cnt - 1) + e] = lds[cnt * RS + slab_code_dev<PAT>(e)];
         }
     }
-}
-
-// The slab region's position relative to a 16-byte boundary is wave-uniform (it depends on the row's base
-// address and c0 only: SLABN * k0 is a multiple of the vector width because k0 is a multiple of 4).
-template <typename T, int PAT, int GV, bool NT>
-__device__ __forceinline__ void stream_slabs(const T *lds, T *gslab, int cnt, int lane)
-{
-    if constexpr (GV == 1) {
-        store_slabs<T, PAT, 1, NT, 0>(lds, gslab, cnt, lane);
-    } else {
-        const int shift = __builtin_amdgcn_readfirstlane((int)((reinterpret_cast<unsigned long long>(gslab) / sizeof(T)) % GV));
-        if (shift == 0) store_slabs<T, PAT, GV, NT, 0>(lds, gslab, cnt, lane);
-        else if (shift == 1) store_slabs<T, PAT, GV, NT, 1>(lds, gslab, cnt, lane);
-        else if constexpr (GV == 4) {
-            if (shift == 2) store_slabs<T, PAT, GV, NT, 2>(lds, gslab, cnt, lane);
-            else store_slabs<T, PAT, GV, NT, 3>(lds, gslab, cnt, lane);
-        }
-    }
-}
+};
 
 // The 8 defects of one node are 8 contiguous elements at F[1+8k]; element 1+8k sits one element
 // past a 16-byte boundary, so the aligned middle goes out as vectors and the ends as scalars.
@@ -507,10 +518,7 @@ __device__ __forceinline__ void tile_body(const FgArgs &a, T *lds, int item, int
                                           Hook after_window = Hook())
 {
     typedef typename Vec<T, VEC>::type vec;
-    // slab stores: 16 bytes per lane whatever the region's alignment (stream_slabs shifts the stream), where
-    // the slab length allows (46 floats are 23 pairs, not quads)
-    constexpr int GV = (PAT == PATTERN_COMPACT && sizeof(T) == 4) ? 2 : (int)(16 / sizeof(T));
-    constexpr int SLABN = SlabGeom<PAT, GV>::SLABN;
+    constexpr int SLABN = StreamGeom<(int)sizeof(T), PAT>::SLABN;
     constexpr int NW = ((NI * TILE + 9 + VEC - 1) / VEC + TILE - 1) / TILE;   // window vectors per lane
     const int N = a.N;
     const TileAt at = tile_at(a, item);
@@ -552,6 +560,9 @@ __device__ __forceinline__ void tile_body(const FgArgs &a, T *lds, int item, int
     // the trajectory's mission: a template constant, or (mixed batch) wave-uniform from its record
     const int ms = MISSION == MISSION_MIXED ? __builtin_amdgcn_readfirstlane(tr.mission) : MISSION;
     const T dt = xrow[0];
+    // the slab stream's per-lane offsets travel with the window (SlabStream)
+    SlabStream<T, PAT, NT, TILE> stream;
+    if (a.needG) stream.load(Grow + a.c0[ms] + (long)SLABN * k0, lane);
     __syncthreads();
     TOLFG_STAMP(a, 1);
     const bool act = lane < cnt;
@@ -620,9 +631,9 @@ __device__ __forceinline__ void tile_body(const FgArgs &a, T *lds, int item, int
     pub.arrive(lane, a.needF != 0, (double)sumT, (double)sumP);
 
     if (a.needG) {
-        // idle lanes (lane >= cnt) leave no row: the workgroup's LDS holds a.nt rows, not TILE
+        // idle lanes (lane >= cnt) leave no row: the workgroup's LDS holds a.nt + 1 rows, not TILE + 1
         if (act) {
-            T *row = lds + lane * RS;
+            T *row = lds + (lane + 1) * RS;          // rows follow one spare row (stream_slabs)
 #ifdef TOLFG_STAMPS
             if (TOLFG_VARIANT(a) & 256) {
 #pragma unroll
@@ -640,7 +651,7 @@ __device__ __forceinline__ void tile_body(const FgArgs &a, T *lds, int item, int
 #elif defined(TOLFG_PRIO) && TOLFG_PRIO == 2      // experiment: waves still loading / computing issue first
         __builtin_amdgcn_s_setprio(0);
 #endif
-        if (!(TOLFG_VARIANT(a) & 2048)) stream_slabs<T, PAT, GV, NT>(lds, Grow + a.c0[ms] + (long)SLABN * k0, cnt, lane);
+        if (!(TOLFG_VARIANT(a) & 2048)) stream.run(lds, cnt, lane);
         TOLFG_STAMP(a, 4);
     }
     TOLFG_STAMP(a, 5);
@@ -983,7 +994,7 @@ __global__ __launch_bounds__(8 * TILE) void fg_single_kernel(const FgArgs a)
     T *lds = reinterpret_cast<T *>(lds_raw);
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x / TILE), lane = threadIdx.x % TILE;   // w is wave-uniform: keep it scalar
     const int b = blockIdx.x;
-    double *red = reinterpret_cast<double *>(lds + (long)a.tiles * TILE * RS);     // [tiles][2]
+    double *red = reinterpret_cast<double *>(lds + (long)a.tiles * WAVE_LDS);     // [tiles][2]
     T *edge = reinterpret_cast<T *>(red + 2 * a.tiles);                            // [24] dt, node 0, node N
     // wave 0 finalizes: it asks for the values finalize_body reads right away, so that they are back
     // (x may live in host memory) long before they are needed
@@ -994,7 +1005,7 @@ __global__ __launch_bounds__(8 * TILE) void fg_single_kernel(const FgArgs a)
     }
     T sumT, sumP;
     Publish pub{nullptr, nullptr, 0u};
-    tile_body<T, MISSION, WIND, VEC, PAT, false>(a, lds + (long)w * TILE * RS, b * a.tiles + w, lane, sumT, sumP, pub);
+    tile_body<T, MISSION, WIND, VEC, PAT, false>(a, lds + (long)w * WAVE_LDS, b * a.tiles + w, lane, sumT, sumP, pub);
     if (lane == 0) { red[2 * w] = (double)sumT; red[2 * w + 1] = (double)sumP; }
     if (w == 0 && lane < 23) edge[lane] = pre;
     __syncthreads();
@@ -1029,7 +1040,7 @@ hipError_t launch_vec(const FgArgs &a, int vec, dim3 grid, hipStream_t s, hipEve
         if constexpr (MISSION == MISSION_MIXED) {
             return hipErrorInvalidValue;           // a mixed batch always takes the tile-per-workgroup path
         } else {
-            const unsigned ldsz = (unsigned)(a.tiles * TILE * RS * sizeof(T) + 16 * a.tiles + 24 * sizeof(T));
+            const unsigned ldsz = (unsigned)(a.tiles * WAVE_LDS * sizeof(T) + 16 * a.tiles + 24 * sizeof(T));
             const dim3 g1(a.B), b1(TILE * a.tiles);
             if (t0 && (e = hipEventRecord(t0, s)) != hipSuccess) return e;
             if (vec == VMAX) {
@@ -1304,9 +1315,9 @@ hipError_t launch_bounds(const BoundsArgs &a, int dtype, hipStream_t s)
 
 int fg_lds_bytes(int dtype, int nt)
 {
-    // nt rows of RS elements (the x window, 11*nt + 10 elements at most, is staged in the same space first)
+    // a spare row and nt rows of RS elements (the x window, 11*nt + 10 elements at most, is staged in the same space first)
     const int rows = nt > 0 && nt < TILE ? nt : TILE;
-    return ((rows * RS * (dtype == 0 ? 8 : 4)) + 15) & ~15;
+    return (((rows + 1) * RS * (dtype == 0 ? 8 : 4)) + 15) & ~15;
 }
 
 int fg_lds_request(int dtype, int waves_per_cu, int nt)
