@@ -54,10 +54,22 @@ int main(int argc, char **argv) {
         }
     }
     {   // launch plan (plan.cpp): outputs that fit the Infinity Cache vs outputs beyond it
-        const LaunchPlan small = plan_launch(100e6, 0, PATTERN_REFERENCE), big = plan_launch(800e6, 0, PATTERN_REFERENCE);
-        const LaunchPlan big32 = plan_launch(800e6, 1, PATTERN_REFERENCE), bigc = plan_launch(800e6, 0, PATTERN_COMPACT);
-        if (small.nt_stores || small.waves_per_cu || !small.fused || !small.xcd || small.max_nt != 64) rc = 4;
-        if (!big.nt_stores || big.waves_per_cu != 8 || !big.fused || big32.waves_per_cu != 12 || bigc.fused) rc = 5;
+        const LaunchPlan small = plan_launch(LaunchShape{512, 200, 0, PATTERN_REFERENCE, MISSION_S10, 1, 100e6});
+        const LaunchPlan mid = plan_launch(LaunchShape{1024, 200, 0, PATTERN_REFERENCE, MISSION_S10, 1, 190e6});
+        const LaunchPlan big = plan_launch(LaunchShape{4096, 200, 0, PATTERN_REFERENCE, MISSION_S10, 1, 800e6});
+        const LaunchPlan big32 = plan_launch(LaunchShape{4096, 200, 1, PATTERN_REFERENCE, MISSION_S10, 1, 800e6});
+        const LaunchPlan bigc = plan_launch(LaunchShape{4096, 200, 0, PATTERN_COMPACT, MISSION_S10, 1, 800e6});
+        const LaunchPlan mix32 = plan_launch(LaunchShape{8192, 200, 1, PATTERN_REFERENCE, MISSION_MIXED, 1, 800e6});
+        const LaunchPlan mix32u = plan_launch(LaunchShape{8192, 200, 1, PATTERN_REFERENCE, MISSION_MIXED, 0, 800e6});
+        if (small.nt_stores || small.waves_per_cu || !small.fused || !small.xcd || small.max_nt != 64 || small.stagger) rc = 4;
+        if (!big.nt_stores || big.waves_per_cu != 8 || !big.fused || big32.waves_per_cu != 12 || bigc.fused || big.stagger) rc = 5;
+        if (!mid.stagger || mid.nt_stores || big32.max_nt != 64 || mix32.max_nt != 128 || mix32.waves_per_cu != 8 || mix32u.max_nt != 64) rc = 6;
+        for (int cap : {128, 100}) {
+            int tiles, nt; plan_tiles(200, 1, cap, &tiles, &nt);
+            if (tiles != 2 || nt != 100) rc = 7;
+            plan_tiles(200, 0, cap, &tiles, &nt);
+            if (nt > 64) rc = 7;
+        }
     }
     try { aircraft bad("no_such_airframe", root); rc = 3; } catch (const std::length_error &) {}
     std::printf("host sanitize run rc=%d\n", rc);

@@ -10,7 +10,6 @@ enum { MISSION_S10 = 0, MISSION_G7 = 1, MISSION_MIXED = 2 };   // MIXED: every t
 enum { WIND_NONE = 0, WIND_SHEAR = 1, WIND_TABLE = 2, WIND_GRID = 3 };   // kernel-side enumeration
 enum { MAX_AIRCRAFT = 8 };
 enum { PATTERN_REFERENCE = 0, PATTERN_COMPACT = 1 };   // slab_table.h
-enum { QUEUE_STRIDE = 1024, QUEUE_WORDS = 33 * 1024 };  // unsigned words between the tile-queue heads (4 KiB); size of the array
 constexpr unsigned kEmptySlotWord = 0xFFFBADADu;        // fused path: every 32-bit word of an empty partial slot
 
 // Air-frame constants as the kernels want them (reciprocals taken once on the host).
@@ -72,17 +71,14 @@ struct FgArgs {
     int  single;           // 1 = one workgroup per trajectory, one launch (tiles <= 8, small B)
     int  fused;            // 1 = the tile wave that arrives last at its trajectory's counter finalizes (one launch);
                            // 0 = finalize_kernel follows fg_kernel
+    int  stagger;          // 1 = waves take an issue priority from their slot on the SIMD (launches whose waves all start together)
     int  nt_stores;        // 1 = the slab stream carries the non-temporal hint (outputs beyond the Infinity Cache)
     int  xcd_chunk;        // workgroup id < 8 * xcd_chunk -> tile (id % 8) * xcd_chunk + id / 8 (every XCD walks a contiguous
                            // run of xcd_chunk tiles); id >= 8 * xcd_chunk -> tile id.  0 <= xcd_chunk <= ceil(B*tiles/8)
-    int  persist;          // experiment only (TOLFG_PERSIST_EXPERIMENT builds): persist_groups workgroups walk the tiles
-                           // through per-XCD queues; the product build refuses it
-    int  persist_groups;
     double *partial;       // [B*tiles][2] objective partials (sum T^2, sum (r-R)^2), device; on the fused path
                            // every slot is "empty" (kEmptySlotWord) between launches
     unsigned *counter;     // [B + 1]: [0, B) arrival counters of the fused path, [B] departures of the callback's
                            // completion word; all zero before a launch, put back to zero by the launch itself
-    unsigned *queues;      // persistent form: QUEUE_WORDS words (32 queue heads + departures, QUEUE_STRIDE apart), zero between launches
     // Completion word for the SNOPT callback (host-mapped, or nullptr): when every wave's stores are visible
     // to the host, the last wave to leave writes done_seq there, so the caller can spin on it instead of
     // synchronising the stream.
@@ -91,16 +87,16 @@ struct FgArgs {
     void   *obj;           // optional [B]: finalize_kernel also writes the objectives here, contiguous
     double kT[2], kp[2], kv[2], kdt[2];   // gains, per mission (problems/<mission>/gains.param)
     AcCoef ac[MAX_AIRCRAFT];
-#ifdef TOLFG_STAMPS
-    // diagnostic build only (tools/fgprobe.cpp): per-wave s_memtime stamps, 8 per workgroup, and a
-    // variant selector for ablations.  The product library is never compiled with TOLFG_STAMPS.
+#if defined(TOLFG_STAMPS) || defined(TOLFG_ABLATE)
+    // diagnostic builds only (tools/fgprobe.cpp, tools/fgbench.cpp -DTOLFG_ABLATE): per-wave s_memtime stamps, 8 per
+    // workgroup, and a variant selector for ablations.  The product library is never compiled with either macro.
     unsigned long long *stamps;
     int variant;
 #endif
 };
 
 // Tiling of one trajectory's N dynamic nodes: `tiles` tiles of `nt` <= max_nt nodes (the last may be
-// short).  max_nt is a multiple of 4 in [4, 64]; 0 = 64.
+// short).  max_nt is a multiple of 4 in [4, 64] (fp32: up to 128, two nodes per lane); 0 = 64.
 void plan_tiles(int N, int dtype, int max_nt, int *tiles, int *nt);
 // Per-launch choices the host makes from the size of the outputs (plan.cpp holds the measurements)
 struct LaunchPlan {
@@ -110,8 +106,17 @@ struct LaunchPlan {
     int xcd;               // deal the tiles to the XCDs in contiguous eighths
     int fused;             // the last-arriving tile wave finalizes (one launch) vs finalize_kernel as a second launch
     int tail_count, tail_nt;   // the last tail_count trajectories in tiles of <= tail_nt nodes (0 = no tail)
+    int stagger;           // issue priorities by SIMD slot (FgArgs::stagger)
 };
-LaunchPlan plan_launch(double out_bytes, int dtype, int pattern);
+// what the plan looks at: the launch's shape and the bytes it writes
+struct LaunchShape {
+    int B, N;              // trajectories, dynamic nodes per trajectory
+    int dtype, pattern;    // 0 = f64 | 1 = f32; PATTERN_*
+    int mission;           // MISSION_*
+    int aligned;           // rows of X and F on 16-byte boundaries (16-byte window loads / defect stores possible)
+    double out_bytes;      // F + G bytes this launch writes
+};
+LaunchPlan plan_launch(const LaunchShape &shape);
 
 // One evaluation on stream s: F and G of B trajectories.  dtype: 0 = f64, 1 = f32.  vec = elements per
 // 16-byte access the caller has verified alignment of X, F and their row strides for (f64: 2 or 1;

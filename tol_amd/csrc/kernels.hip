@@ -96,11 +96,31 @@ constexpr int gcd_c(int a, int b) { return b == 0 ? a : gcd_c(b, a % b); }
 #define TOLFG_WHERE(a, slot) do {} while (0)
 #define TOLFG_STAMP(a, slot) do {} while (0)
 #define TOLFG_REALTIME(a, slot) do {} while (0)
+#ifdef TOLFG_ABLATE                 // tools/fgbench.cpp -DTOLFG_ABLATE: the ablation switches without the stamps
+#define TOLFG_VARIANT(a) ((a).variant)
+#else
 #define TOLFG_VARIANT(a) 0
+#endif
 #endif
 
 template <typename T, int VEC> struct Vec { typedef T type __attribute__((ext_vector_type(VEC))); };
 template <typename T> struct Vec<T, 1> { typedef T type; };
+
+// What one lane computes with.  NP = 1: one node per lane, the lane value is the element type.  NP = 2 (fp32
+// only): two nodes per lane, the lane value is a pair of floats in a 64-bit register pair, and the compiler
+// turns the node arithmetic into v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 (two nodes per instruction:
+// 128-node tiles, half the waves, half the vector issue per node).  Component c of lane l is node l + 64*c.
+typedef float f2 __attribute__((ext_vector_type(2)));
+template <typename T, int NP> struct LaneOf { typedef T type; };
+template <> struct LaneOf<float, 2> { typedef f2 type; };
+template <typename L> struct LaneTraits { typedef L elem; enum { NP = 1 }; };
+template <> struct LaneTraits<f2> { typedef float elem; enum { NP = 2 }; };
+__device__ __forceinline__ double comp(double v, int) { return v; }
+__device__ __forceinline__ float comp(float v, int) { return v; }
+__device__ __forceinline__ float comp(f2 v, int c) { return v[c]; }
+__device__ __forceinline__ void set_comp(double &l, int, double v) { l = v; }
+__device__ __forceinline__ void set_comp(float &l, int, float v) { l = v; }
+__device__ __forceinline__ void set_comp(f2 &l, int c, float v) { l[c] = v; }
 
 // sin and cos of a double, both at once.  The angles on this path (flight-path angle, course, bank) are a few
 // radians at most, so the common case is a two-constant Cody-Waite reduction by pi/2 (exact products through
@@ -140,8 +160,55 @@ __device__ __forceinline__ void sincos_t(double a, double &s, double &c)
     c = ((q + 1) & 2) ? -c0 : c0;
 }
 __device__ __forceinline__ void sincos_t(float a, float &s, float &c) { sincosf(a, &s, &c); }
+// Two floats at once: three-constant Cody-Waite reduction by pi/2 and the degree-7 / degree-8 minimax kernels
+// on [-pi/4, pi/4] as packed arithmetic (about 1 ulp); the quadrant logic is per component.  Beyond 2^13 (or
+// NaN) the library routine, component by component.
+__device__ __forceinline__ void sincos_t(f2 a, f2 &s, f2 &c)
+{
+    if (!(fabsf(a.x) < 8192.0f) || !(fabsf(a.y) < 8192.0f)) {
+        float s0, c0, s1, c1;
+        sincosf(a.x, &s0, &c0);
+        sincosf(a.y, &s1, &c1);
+        s = f2{s0, s1}; c = f2{c0, c1};
+        return;
+    }
+    const f2 t = a * 0.636619772367581343f;                         // 2/pi
+    const f2 k = f2{__builtin_rintf(t.x), __builtin_rintf(t.y)};
+    f2 r = __builtin_elementwise_fma(k, f2(-1.5703125f), a);         // pi/2 in three pieces, the first two exact products
+    r = __builtin_elementwise_fma(k, f2(-4.837512969970703125e-4f), r);
+    r = __builtin_elementwise_fma(k, f2(-7.54978995489188216e-8f), r);
+    const f2 z = r * r;
+    f2 ps = __builtin_elementwise_fma(z, f2(-1.9515295891e-4f), f2(8.3321608736e-3f));
+    ps = __builtin_elementwise_fma(z, ps, f2(-1.6666654611e-1f));
+    const f2 sn = __builtin_elementwise_fma(z * r, ps, r);
+    f2 pc = __builtin_elementwise_fma(z, f2(2.443315711809948e-5f), f2(-1.388731625493765e-3f));
+    pc = __builtin_elementwise_fma(z, pc, f2(4.166664568298827e-2f));
+    const f2 cs = __builtin_elementwise_fma(z * z, pc, __builtin_elementwise_fma(z, f2(-0.5f), f2(1.0f)));
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int q = (int)k[i];
+        const bool odd = q & 1;
+        const unsigned s0 = __builtin_bit_cast(unsigned, odd ? cs[i] : sn[i]);
+        const unsigned c0 = __builtin_bit_cast(unsigned, odd ? sn[i] : cs[i]);
+        s[i] = __builtin_bit_cast(float, s0 ^ (((unsigned)q << 30) & 0x80000000u));
+        c[i] = __builtin_bit_cast(float, c0 ^ (((unsigned)(q + 1) << 30) & 0x80000000u));
+    }
+}
 __device__ __forceinline__ double sqrt_t(double a) { return sqrt(a); }
 __device__ __forceinline__ float sqrt_t(float a) { return sqrtf(a); }
+__device__ __forceinline__ f2 sqrt_t(f2 a) { return f2{__builtin_amdgcn_sqrtf(a.x), __builtin_amdgcn_sqrtf(a.y)}; }   // 1 ulp
+// reciprocal and quotient: IEEE division for the one-node-per-lane forms (results as in round 2); the packed form
+// takes v_rcp_f32 (1 ulp) and one Newton step in packed arithmetic
+__device__ __forceinline__ double rcp_t(double a) { return 1.0 / a; }
+__device__ __forceinline__ float rcp_t(float a) { return 1.0f / a; }
+__device__ __forceinline__ f2 rcp_t(f2 a)
+{
+    const f2 r = f2{__builtin_amdgcn_rcpf(a.x), __builtin_amdgcn_rcpf(a.y)};
+    return __builtin_elementwise_fma(__builtin_elementwise_fma(-a, r, f2(1.0f)), r, r);
+}
+__device__ __forceinline__ double div_t(double a, double b) { return a / b; }
+__device__ __forceinline__ float div_t(float a, float b) { return a / b; }
+__device__ __forceinline__ f2 div_t(f2 a, f2 b) { return a * rcp_t(b); }
 
 // Output is written once and never read back by the GPU: with TOLFG_NT_STORES the streaming stores
 // carry the non-temporal hint so that they do not displace the x rows from L2 / Infinity Cache.
@@ -196,28 +263,32 @@ __device__ __forceinline__ T dotw(T e0, T e1, T e2, const T (&V)[3])
 // the Jacobian values are formed: rates() fills f[0..7] and keeps the shared sub-expressions,
 // jacobian() writes the 32 computed Jacobian values straight into the node's LDS row.
 // s = x y z Va gam chi phi CL dphi dCL T;  we = the node's 12 ENU wind values (WIND_TABLE only).
+// T is the lane type (LaneOf): double, float, or a pair of floats = two nodes.
 template <typename T, int WIND> struct NodeCtx {
     T Va, CL, dt, sg, cg, sx, cx, sp, cp, ea0, ea1, ea2, eg0, eg1, eg2;
     T A[3], B[3], C[3], H[3];
     T v0, v1, v2, vA, vB, vC, vH, iVa, icg, qV, q, CD, N5, N6, inv_m, kind, dphi, dCL;
 
+    typedef typename LaneTraits<T>::elem E;      // element type: T itself, or float when T is a pair of floats
+    static constexpr int NP = LaneTraits<T>::NP;
+
     // Trilinear interpolation of the gridded v component and its gradient at one ENU point
     // (ref: src/problem.cpp:551-692).  Returns v, d v / d(east, north, up).
-    __device__ __forceinline__ static void grid_wind(const GridDev &gr, T pn, T pe, T pd, T &v, T &dve, T &dvn, T &dvu)
+    __device__ __forceinline__ static void grid_wind(const GridDev &gr, E pn, E pe, E pd, E &v, E &dve, E &dvn, E &dvu)
     {
-        const T xs = pe + T(gr.e0), ys = pn + T(gr.n0), zs = -pd + T(gr.u0);
-        const T dx = T(gr.dx), dy = T(gr.dy), dz = T(gr.dz);
+        const E xs = pe + E(gr.e0), ys = pn + E(gr.n0), zs = -pd + E(gr.u0);
+        const E dx = E(gr.dx), dy = E(gr.dy), dz = E(gr.dz);
         // lower corner: the first grid coordinate within one spacing below the point, edge cell outside
-        const int xi = min(max((int)floor((xs - T(gr.x0)) / dx), 0), gr.nx - 2);
-        const int yi = min(max((int)floor((ys - T(gr.y0)) / dy), 0), gr.ny - 2);
-        const int zi = min(max((int)floor((zs - T(gr.z0)) / dz), 0), gr.nz - 2);
-        const T *g = static_cast<const T *>(gr.v) + ((long)xi * gr.ny + yi) * gr.nz + zi;
+        const int xi = min(max((int)floor((xs - E(gr.x0)) / dx), 0), gr.nx - 2);
+        const int yi = min(max((int)floor((ys - E(gr.y0)) / dy), 0), gr.ny - 2);
+        const int zi = min(max((int)floor((zs - E(gr.z0)) / dz), 0), gr.nz - 2);
+        const E *g = static_cast<const E *>(gr.v) + ((long)xi * gr.ny + yi) * gr.nz + zi;
         const long sx_ = (long)gr.ny * gr.nz, sy_ = gr.nz;
-        const T v0 = g[0], v1 = g[sx_], v2 = g[sy_], v3 = g[sx_ + sy_];
-        const T v4 = g[1], v5 = g[sx_ + 1], v6 = g[sy_ + 1], v7 = g[sx_ + sy_ + 1];
-        const T ze = (xs - (T(gr.x0) + T(xi) * dx)) / dx, et = (ys - (T(gr.y0) + T(yi) * dy)) / dy;
-        const T mu = (zs - (T(gr.z0) + T(zi) * dz)) / dz;
-        const T a = T(1) - ze, b = T(1) - et, c = T(1) - mu;
+        const E v0 = g[0], v1 = g[sx_], v2 = g[sy_], v3 = g[sx_ + sy_];
+        const E v4 = g[1], v5 = g[sx_ + 1], v6 = g[sy_ + 1], v7 = g[sx_ + sy_ + 1];
+        const E ze = (xs - (E(gr.x0) + E(xi) * dx)) / dx, et = (ys - (E(gr.y0) + E(yi) * dy)) / dy;
+        const E mu = (zs - (E(gr.z0) + E(zi) * dz)) / dz;
+        const E a = E(1) - ze, b = E(1) - et, c = E(1) - mu;
         v = a * b * c * v0 + ze * b * c * v1 + a * et * c * v2 + ze * et * c * v3 +
             a * b * mu * v4 + ze * b * mu * v5 + a * et * mu * v6 + ze * et * mu * v7;
         dve = ((v1 - v0) * b * c + (v3 - v2) * et * c + (v5 - v4) * b * mu + (v7 - v6) * et * mu) / dx;
@@ -256,7 +327,12 @@ template <typename T, int WIND> struct NodeCtx {
         } else if constexpr (WIND == WIND_GRID) {
             // only Wx (= ENU v) is non-zero: dWx/dx_NED = dv/dnorth, dWx/dy_NED = dv/deast, dWx/dz_NED = -dv/dup
             T v, dve, dvn, dvu;
-            grid_wind(gr, s[0], s[1], s[2], v, dve, dvn, dvu);
+#pragma unroll
+            for (int c = 0; c < NP; c++) {
+                E v_, dve_, dvn_, dvu_;
+                grid_wind(gr, comp(s[0], c), comp(s[1], c), comp(s[2], c), v_, dve_, dvn_, dvu_);
+                set_comp(v, c, v_); set_comp(dve, c, dve_); set_comp(dvn, c, dvn_); set_comp(dvu, c, dvu_);
+            }
             W[0] = v;
             const T J00 = dvn, J01 = dve, J02 = -dvu;
             A[0] = ea0 * J00; A[1] = ea0 * J01; A[2] = ea0 * J02;
@@ -268,7 +344,7 @@ template <typename T, int WIND> struct NodeCtx {
         vA = dotw<WIND>(v0, v1, v2, A); vB = dotw<WIND>(v0, v1, v2, B);
         vC = dotw<WIND>(v0, v1, v2, C); vH = dotw<WIND>(v0, v1, v2, H);
         const T g9 = T(kGrav);
-        iVa = T(1) / Va; icg = T(1) / cg;
+        iVa = rcp_t(Va); icg = rcp_t(cg);
         qV = qk * Va;               // rho S Va / (2 m)
         q = qV * Va;                // rho S Va^2 / (2 m)
         CD = Cd0 + CL * CL * kind;
@@ -282,7 +358,8 @@ template <typename T, int WIND> struct NodeCtx {
         f[7] = s[9];
     }
 
-    __device__ __forceinline__ void jacobian(const T (&f)[8], T *g) const
+    // g: the node's LDS row (E *), or the pair of rows of the lane's two nodes (RowPair)
+    template <typename Row> __device__ __forceinline__ void jacobian(const T (&f)[8], Row g) const
     {
         const T g9 = T(kGrav);
         const T dtVa = dt * Va;
@@ -401,30 +478,41 @@ template <typename T, int PAT, bool NT, int TN> struct SlabStream {
         for (int c = 0; c < CHU; c++) tb[c] = tp[c * TILE];
     }
 
+    // the vector of round R (LDS gather through the lane's offsets); rounds past the tile read rows nobody wrote,
+    // or past the allocation (LDS then returns zeros): harmless, such a vector is never stored
+    __device__ __forceinline__ vec gather(const char *lb, int R) const
+    {
+        const int j = R / P, t = R % P;
+        const char *grp = lb + j * Gm::NPP * RS * ES;
+        vec val;
+#pragma unroll
+        for (int v = 0; v < GV; v++) {
+            const int i = t * GV + v;
+            const unsigned wv = tb[(i / 2) / 4][(i / 2) % 4];
+            const unsigned off = (i & 1) ? (wv >> 16) : (wv & 0xffffu);
+            val[v] = *reinterpret_cast<const T *>(grp + off);
+        }
+        return val;
+    }
+
     __device__ __forceinline__ void run(const T *lds, int cnt, int lane) const
     {
         const int E = SLABN * cnt;                         // elements of the region
         const int qhi = (E + shift) / GV;                  // whole vectors are q in [shift ? 1 : 0, qhi)
         const char *lb = reinterpret_cast<const char *>(lds);
         vec *gp = reinterpret_cast<vec *>(gslab - shift) + lane;
+        // one round ahead: the LDS reads of round R + 1 are in flight while round R's vector is stored (a wave
+        // alone on its SIMD -- small batches, the SNOPT callback -- otherwise pays the LDS latency once per round)
+        vec cur = gather(lb, 0);
 #pragma unroll
         for (int R = 0; R < RMAX; R++) {
             if (TILE * R >= qhi) break;                    // wave-uniform
-            const int j = R / P, t = R % P;
-            const char *grp = lb + j * Gm::NPP * RS * ES;
+            vec nxt = cur;
+            if (R + 1 < RMAX) nxt = gather(lb, R + 1);
             const int q = TILE * R + lane;
             const bool whole = R > 0 && TILE * (R + 1) <= qhi;     // wave-uniform: no lane is cut off
-            if (whole || (q < qhi && (R > 0 || shift == 0 || lane > 0))) {
-                vec val;
-#pragma unroll
-                for (int v = 0; v < GV; v++) {
-                    const int i = t * GV + v;
-                    const unsigned wv = tb[(i / 2) / 4][(i / 2) % 4];
-                    const unsigned off = (i & 1) ? (wv >> 16) : (wv & 0xffffu);
-                    val[v] = *reinterpret_cast<const T *>(grp + off);
-                }
-                stream_store<NT>(gp + TILE * R, val);
-            }
+            if (whole || (q < qhi && (R > 0 || shift == 0 || lane > 0))) stream_store<NT>(gp + TILE * R, cur);
+            cur = nxt;
         }
         // the elements before the first and after the last whole vector
         const int ntail = E + shift - qhi * GV;            // in [0, GV)
@@ -485,7 +573,6 @@ struct Publish {
 
 // One tile: everything a wavefront does for `cnt` consecutive nodes of trajectory b.  lds is the
 // wave's own TILE*RS-element region; sumT / sumP return the tile's objective terms (wave-uniform).
-struct NoHook { __device__ __forceinline__ void operator()() const {} };
 
 // Where a tile lies: trajectory, first node, tiling of that trajectory, number of the trajectory's first tile.
 struct TileAt { int b, k0, tiles, nt, first; };
@@ -510,16 +597,27 @@ __device__ __forceinline__ long first_tile_of(const FgArgs &a, int b)
     return b < tb ? (long)b * a.tiles : body_tiles(a) + (long)(b - tb) * a.tail_tiles;
 }
 
-// `after_window` runs once the x window has been consumed (the wave's loads are back): the persistent form
-// asks for its next tile there, so that the atomic's round trip hides behind the arithmetic and the stores
-// instead of sitting in front of the window loads (vmcnt counts in order).
-template <typename T, int MISSION, int WIND, int VEC, int PAT, bool NT, typename Hook = NoHook>
-__device__ __forceinline__ void tile_body(const FgArgs &a, T *lds, int item, int lane, T &sumT_out, T &sumP_out, Publish &pub,
-                                          Hook after_window = Hook())
+// The LDS rows of a lane's two nodes, written through one subscript (NodeCtx::jacobian, NP = 2)
+struct RowPair {
+    float *r0, *r1;
+    struct Ref {
+        float *p0, *p1;
+        __device__ __forceinline__ void operator=(f2 v) const { *p0 = v.x; *p1 = v.y; }
+    };
+    __device__ __forceinline__ Ref operator[](int i) const { return Ref{r0 + i, r1 + i}; }
+};
+
+// One tile: everything a wavefront does for `cnt` consecutive nodes of trajectory b.  lds is the wave's own region
+// (a spare row and a.nt rows of RS elements); sumT / sumP return the tile's objective terms (wave-uniform).
+// NP nodes per lane (LaneOf): node `lane` and, with NP = 2, node `lane + 64` of the tile.
+template <typename T, int MISSION, int WIND, int VEC, int PAT, bool NT, int NP = 1>
+__device__ __forceinline__ void tile_body(const FgArgs &a, T *lds, int item, int lane, T &sumT_out, T &sumP_out, Publish &pub)
 {
     typedef typename Vec<T, VEC>::type vec;
+    typedef typename LaneOf<T, NP>::type L;
+    constexpr int TN = TILE * NP;                                             // nodes a tile may hold
     constexpr int SLABN = StreamGeom<(int)sizeof(T), PAT>::SLABN;
-    constexpr int NW = ((NI * TILE + 9 + VEC - 1) / VEC + TILE - 1) / TILE;   // window vectors per lane
+    constexpr int NW = ((NI * TN + 9 + VEC - 1) / VEC + TILE - 1) / TILE;     // window vectors per lane
     const int N = a.N;
     const TileAt at = tile_at(a, item);
     const int b = at.b, k0 = at.k0;
@@ -530,13 +628,10 @@ __device__ __forceinline__ void tile_body(const FgArgs &a, T *lds, int item, int
 
     // ---- x window = x[11*k0 .. 11*(k0+cnt)+9): one element before node k0 (keeps the start 16-byte
     // aligned) up to the 8 states of node k0+cnt, rounded up to whole vectors (stays inside the row);
-    // contiguous 16-byte loads -> LDS -> this lane's node (transpose)
+    // contiguous 16-byte loads -> LDS -> this lane's node(s) (transpose)
     TOLFG_REALTIME(a, 7);
     TOLFG_WHERE(a, 9);
     TOLFG_STAMP(a, 0);
-#if defined(TOLFG_PRIO) && TOLFG_PRIO == 2
-    __builtin_amdgcn_s_setprio(3);
-#endif
     {
         const int nvec = (NI * cnt + 9 + VEC - 1) / VEC;
         const T *xwin = xrow + NI * k0;
@@ -544,11 +639,11 @@ __device__ __forceinline__ void tile_body(const FgArgs &a, T *lds, int item, int
 #pragma unroll
         for (int j = 0; j < NW; j++) {
             const int i = lane + TILE * j;
-#ifdef TOLFG_NT_LOADS
-            if (i < nvec) win[j] = __builtin_nontemporal_load(reinterpret_cast<const vec *>(xwin + (long)i * VEC));
-#else
-            if (i < nvec) win[j] = *reinterpret_cast<const vec *>(xwin + (long)i * VEC);
+#if defined(TOLFG_STAMPS) || defined(TOLFG_ABLATE)
+            win[j] = vec{};
+            if (TOLFG_VARIANT(a) & 4096) continue;     // ablation: no x window
 #endif
+            if (i < nvec) win[j] = *reinterpret_cast<const vec *>(xwin + (long)i * VEC);
         }
 #pragma unroll
         for (int j = 0; j < NW; j++) {
@@ -561,66 +656,87 @@ __device__ __forceinline__ void tile_body(const FgArgs &a, T *lds, int item, int
     const int ms = MISSION == MISSION_MIXED ? __builtin_amdgcn_readfirstlane(tr.mission) : MISSION;
     const T dt = xrow[0];
     // the slab stream's per-lane offsets travel with the window (SlabStream)
-    SlabStream<T, PAT, NT, TILE> stream;
+    SlabStream<T, PAT, NT, TN> stream;
     if (a.needG) stream.load(Grow + a.c0[ms] + (long)SLABN * k0, lane);
     __syncthreads();
     TOLFG_STAMP(a, 1);
-    const bool act = lane < cnt;
-    const int ll = act ? lane : 0;             // idle lanes redo node k0; nothing of theirs is stored
-    T s[NI], sn[8], we[12];
+    bool act[NP];
+    int ll[NP];                                // idle components redo node k0; nothing of theirs is stored
 #pragma unroll
-    for (int m = 0; m < NI; m++) s[m] = lds[1 + NI * ll + m];
+    for (int c = 0; c < NP; c++) { act[c] = lane + TILE * c < cnt; ll[c] = act[c] ? lane + TILE * c : 0; }
+    L s[NI], sn[8], we[12];
 #pragma unroll
-    for (int r = 0; r < 8; r++) sn[r] = lds[1 + NI * (ll + 1) + r];
-    if constexpr (WIND == WIND_TABLE) {
-        const T *wrow = static_cast<const T *>(a.wind) + (long)b * 12 * (N + 1);
+    for (int c = 0; c < NP; c++) {
 #pragma unroll
-        for (int f = 0; f < 12; f++) we[f] = wrow[(long)f * (N + 1) + k0 + ll];
-    } else {
+        for (int m = 0; m < NI; m++) set_comp(s[m], c, lds[1 + NI * ll[c] + m]);
 #pragma unroll
-        for (int f = 0; f < 12; f++) we[f] = T(0);
+        for (int r = 0; r < 8; r++) set_comp(sn[r], c, lds[1 + NI * (ll[c] + 1) + r]);
+        if constexpr (WIND == WIND_TABLE) {
+            const T *wrow = static_cast<const T *>(a.wind) + (long)b * 12 * (N + 1);
+#pragma unroll
+            for (int f = 0; f < 12; f++) set_comp(we[f], c, wrow[(long)f * (N + 1) + k0 + ll[c]]);
+        } else {
+#pragma unroll
+            for (int f = 0; f < 12; f++) set_comp(we[f], c, T(0));
+        }
     }
     __syncthreads();                           // the rows below overwrite the window
     TOLFG_STAMP(a, 2);
-    after_window();
 
     const AcCoef &ac = a.ac[tr.ac];
-    T f[8];
-    NodeCtx<T, WIND> nc;
-#ifdef TOLFG_STAMPS
+    L f[8];
+    NodeCtx<L, WIND> nc;
+#if defined(TOLFG_STAMPS) || defined(TOLFG_ABLATE)
     if (TOLFG_VARIANT(a) & 256) {              // ablation: no arithmetic, outputs are garbage
 #pragma unroll
         for (int r = 0; r < 8; r++) f[r] = s[r];
     } else
 #endif
-    nc.rates(s, dt, T(tr.shear), we, T(ac.inv_m), T(ac.qk), T(ac.Cd0), T(ac.kind), f, a.grid);
+    nc.rates(s, L(dt), L(T(tr.shear)), we, L(T(ac.inv_m)), L(T(ac.qk)), L(T(ac.Cd0)), L(T(ac.kind)), f, a.grid);
 
     // ---- defects leave first (src/problem.cpp:1012-1019); sn dies here
-    if (a.needF && act && !(TOLFG_VARIANT(a) & 512)) {
-        T d8[8];
+    if (a.needF && !(TOLFG_VARIANT(a) & 512)) {
+        L d8[8];
 #pragma unroll
-        for (int r = 0; r < 8; r++) d8[r] = sn[r] - f[r] * dt - s[r];
-        store_defects<T, VEC>(Frow + 1 + 8 * (k0 + lane), d8);
+        for (int r = 0; r < 8; r++) d8[r] = sn[r] - f[r] * L(dt) - s[r];
+#pragma unroll
+        for (int c = 0; c < NP; c++)
+            if (act[c]) {
+                T e8[8];
+#pragma unroll
+                for (int r = 0; r < 8; r++) e8[r] = comp(d8[r], c);
+                store_defects<T, VEC>(Frow + 1 + 8 * (k0 + lane + TILE * c), e8);
+            }
     }
 
     // ---- objective terms of this tile's nodes (node N is the finalizing wave's)
     const T kT = T(a.kT[ms]), kp = T(a.kp[ms]);
-    T sumT = act ? s[10] * s[10] : T(0), sumP = T(0);
+    const L th2 = s[10] * s[10];
+    T sumT = T(0), sumP = T(0);
+#pragma unroll
+    for (int c = 0; c < NP; c++) sumT += act[c] ? comp(th2, c) : T(0);
     if (ms == MISSION_S10) {
         // src/problemS10.cpp:247-262 (value), :346-375 (gradient)
-        const T dx = s[0] - T(tr.xg), dy = s[1] - T(tr.yg);
-        const T r = sqrt_t(dx * dx + dy * dy);
-        const T d = r - T(tr.rg);
-        if (act) sumP = d * d;
-        if (a.needG && act && !(TOLFG_VARIANT(a) & 1024)) {
-            T *gc = Grow + 1 + 3 * (k0 + lane);
-            small_store(gc + 0, kp * d * dx / r);
-            small_store(gc + 1, kp * d * dy / r);
-            small_store(gc + 2, kT * s[10]);
+        const L dx = s[0] - L(T(tr.xg)), dy = s[1] - L(T(tr.yg));
+        const L r = sqrt_t(dx * dx + dy * dy);
+        const L d = r - L(T(tr.rg));
+        const L d2 = d * d, gx = div_t(L(kp) * d * dx, r), gy = div_t(L(kp) * d * dy, r), gt = L(kT) * s[10];
+#pragma unroll
+        for (int c = 0; c < NP; c++) {
+            if (act[c]) sumP += comp(d2, c);
+            if (a.needG && act[c] && !(TOLFG_VARIANT(a) & 1024)) {
+                T *gc = Grow + 1 + 3 * (k0 + lane + TILE * c);
+                small_store(gc + 0, comp(gx, c));
+                small_store(gc + 1, comp(gy, c));
+                small_store(gc + 2, comp(gt, c));
+            }
         }
     } else {
         // src/problemG7.cpp:364-368: one thrust entry per node, after (dt, x0, y0)
-        if (a.needG && act) Grow[3 + k0 + lane] = kT * s[10];
+        const L gt = L(kT) * s[10];
+#pragma unroll
+        for (int c = 0; c < NP; c++)
+            if (a.needG && act[c]) Grow[3 + k0 + lane + TILE * c] = comp(gt, c);
     }
     if (a.needF) {
         sumT = wave_sum(sumT);
@@ -631,26 +747,29 @@ __device__ __forceinline__ void tile_body(const FgArgs &a, T *lds, int item, int
     pub.arrive(lane, a.needF != 0, (double)sumT, (double)sumP);
 
     if (a.needG) {
-        // idle lanes (lane >= cnt) leave no row: the workgroup's LDS holds a.nt + 1 rows, not TILE + 1
-        if (act) {
-            T *row = lds + (lane + 1) * RS;          // rows follow one spare row (stream_slabs)
-#ifdef TOLFG_STAMPS
-            if (TOLFG_VARIANT(a) & 256) {
+        // idle lanes (lane >= cnt) leave no row: the workgroup's LDS holds a.nt + 1 rows, not TN + 1; the second
+        // component of a lane whose second node lies beyond the tile writes the spare row, which nobody reads
+        if (act[0]) {
+            T *row = lds + (lane + 1) * RS;          // rows follow one spare row (SlabStream)
+            if constexpr (NP == 1) {
+#if defined(TOLFG_STAMPS) || defined(TOLFG_ABLATE)
+                if (TOLFG_VARIANT(a) & 256) {
 #pragma unroll
-                for (int i = 0; i < 32; i++) row[i] = s[i % NI];
-            } else
+                    for (int i = 0; i < 32; i++) row[i] = s[i % NI];
+                } else
 #endif
-            nc.jacobian(f, row);
-            row[SL_ZERO] = T(0); row[SL_ONE] = T(1); row[SL_MONE] = T(-1);
+                nc.jacobian(f, row);
+                row[SL_ZERO] = T(0); row[SL_ONE] = T(1); row[SL_MONE] = T(-1);
+            } else {
+                T *row1 = act[NP - 1] ? row + TILE * RS : lds;
+                nc.jacobian(f, RowPair{row, row1});
+                row[SL_ZERO] = T(0); row[SL_ONE] = T(1); row[SL_MONE] = T(-1);
+                row1[SL_ZERO] = T(0); row1[SL_ONE] = T(1); row1[SL_MONE] = T(-1);
+            }
         }
         __syncthreads();
         TOLFG_STAMP(a, 3);
         __builtin_amdgcn_sched_barrier(0);
-#if defined(TOLFG_PRIO) && TOLFG_PRIO == 1        // experiment: waves in their store phase issue first
-        __builtin_amdgcn_s_setprio(3);
-#elif defined(TOLFG_PRIO) && TOLFG_PRIO == 2      // experiment: waves still loading / computing issue first
-        __builtin_amdgcn_s_setprio(0);
-#endif
         if (!(TOLFG_VARIANT(a) & 2048)) stream.run(lds, cnt, lane);
         TOLFG_STAMP(a, 4);
     }
@@ -842,8 +961,8 @@ __device__ __forceinline__ void sum_partials(const double *part, int tiles, int 
 }
 
 // One tile and, on the fused path, the finalization of its trajectory when this wave arrived last.
-template <typename T, int MISSION, int WIND, int VEC, int PAT, bool NT, typename Hook = NoHook>
-__device__ __forceinline__ void run_tile(const FgArgs &a, T *lds, int item, int lane, Hook after_window = Hook())
+template <typename T, int MISSION, int WIND, int VEC, int PAT, bool NT, int NP>
+__device__ __forceinline__ void run_tile(const FgArgs &a, T *lds, int item, int lane)
 {
     const TileAt at = tile_at(a, item);
     const int b = at.b;
@@ -853,7 +972,7 @@ __device__ __forceinline__ void run_tile(const FgArgs &a, T *lds, int item, int 
         pub.slot = a.partial + 2 * (long)item;
         pub.counter = a.counter + b;
     }
-    tile_body<T, MISSION, WIND, VEC, PAT, NT>(a, lds, item, lane, sumT, sumP, pub, after_window);
+    tile_body<T, MISSION, WIND, VEC, PAT, NT, NP>(a, lds, item, lane, sumT, sumP, pub);
     if (a.fused) {
         const unsigned old = __builtin_amdgcn_readfirstlane(pub.old);
         if (old == (unsigned)(at.tiles - 1)) {         // wave-uniform: every tile of b has arrived
@@ -868,110 +987,46 @@ __device__ __forceinline__ void run_tile(const FgArgs &a, T *lds, int item, int 
     }
 }
 
-#ifdef TOLFG_PERSIST_EXPERIMENT      // measured and not adopted (profiles/r02_persistent.md); built by tools/fgbench.cpp only
-// Persistent form: the tiles of the batch are cut into 8 contiguous chunks, one per XCD, and each chunk into
-// 4 sub-chunks with a queue head each (32 heads, one per 4 KiB: same-address device atomics run at only
-// ~15-20 M/s, so 8 heads in one line made this form 2x slower and 8 heads on 8 lines still 10 % slower than
-// one workgroup per tile).  The workgroups -- as many as fit the machine at once -- take tiles from a
-// sub-chunk of the XCD they run on, then from its siblings, then from the other XCDs.  Nobody waits.
-struct TileQueues {
-    enum { NQ = 32 };
-    unsigned *head;        // head[q * QUEUE_STRIDE], q < NQ; departures at head[NQ * QUEUE_STRIDE]; zero between launches
-    int xchunk, sub;       // tiles per XCD chunk = ceil(W / 8), per sub-chunk = ceil(xchunk / 4)
-    long W;
-    __device__ __forceinline__ long start(int q) const { return (long)(q >> 2) * xchunk + (long)(q & 3) * sub; }
-    __device__ __forceinline__ int len(int q) const
-    {
-        long end = start(q) + sub;
-        const long xend = (long)((q >> 2) + 1) * xchunk;
-        end = end < xend ? end : xend;
-        end = end < W ? end : W;
-        const long n = end - start(q);
-        return n > 0 ? (int)n : 0;
-    }
-    // position in queue q (lane 0 holds it; a position >= len(q) means "empty")
-    __device__ __forceinline__ unsigned take(int q, int lane) const
-    {
-        unsigned pos = 0;
-        if (lane == 0) pos = __hip_atomic_fetch_add(head + q * QUEUE_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return pos;
-    }
-    // a queue that still has tiles: the siblings of q first, then the other XCDs' queues; -1 when all are empty
-    __device__ __forceinline__ int other(int q, int lane) const
-    {
-        unsigned h = 0xffffffffu;
-        if (lane < NQ) h = __hip_atomic_load(head + lane * QUEUE_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        for (int i = 1; i < 4; i++) {
-            const int c = (q & ~3) | ((q + i) & 3);
-            if ((unsigned)__builtin_amdgcn_readlane((int)h, c) < (unsigned)len(c)) return c;
-        }
-        for (int i = 4; i < NQ; i++) {
-            const int c = ((q & ~3) + i) & (NQ - 1);
-            if ((unsigned)__builtin_amdgcn_readlane((int)h, c) < (unsigned)len(c)) return c;
-        }
-        return -1;
-    }
-};
-#endif
-
 // fg_kernel: one 64-lane workgroup per tile.  Workgroup ids go round-robin over the 8 XCDs; with
 // a.xcd_chunk > 0 workgroup id works on tile (id % 8) * xcd_chunk + id / 8, so that every XCD walks
 // its own contiguous eighth of the batch's memory (measured +6 % on the write stream,
 // profiles/r02_write_shapes.md); otherwise consecutive workgroups walk the memory in order.
-// (With TOLFG_PERSIST_EXPERIMENT and a.persist the grid is only as large as the machine holds and every workgroup
-// walks tiles of its XCD's chunk, TileQueues: 12-25 % slower, profiles/r02_persistent.md.)
 // Fused form (a.fused): the wave that arrives last at its trajectory's counter also finalizes it, so
 // an evaluation is one launch; otherwise finalize_kernel follows.
-template <typename T, int MISSION, int WIND, int VEC, int PAT, bool NT>
+// (A persistent form with per-XCD tile queues was measured 12-25 % slower: profiles/r02_persistent.md keeps the patch.)
+template <typename T, int MISSION, int WIND, int VEC, int PAT, bool NT, int NP>
 __global__ __launch_bounds__(TILE, TOLFG_MIN_WAVES_PER_SIMD) void fg_kernel(const FgArgs a)
 {
-    // dynamic LDS: nt*RS elements are used; the launch may request more to cap the waves per CU
+    // dynamic LDS: (nt + 1) * RS elements are used; the launch may request more to cap the waves per CU
     // (fewer concurrent store streams suit the HBM write path better)
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     T *lds = reinterpret_cast<T *>(lds_raw);
     const int lane = threadIdx.x;
-#ifdef TOLFG_PERSIST_EXPERIMENT
-    if (!a.persist)
-#endif
-    {
-        int item = blockIdx.x;
-        if (item < 8 * a.xcd_chunk) {                  // the rest (the launch's tail) in id order
-            int x = item & 7;
-            if (TOLFG_VARIANT(a) & (1 << 16)) x ^= 1;              // probes (stamped build): which XCD walks which eighth
-            if (TOLFG_VARIANT(a) & (1 << 17)) x = (x + 4) & 7;
-            if (TOLFG_VARIANT(a) & (1 << 18)) x = (x + 2) & 7;
-            item = x * a.xcd_chunk + (item >> 3);
+    int item = blockIdx.x;
+    if (item < 8 * a.xcd_chunk) {                  // the rest (the launch's tail) in id order
+        int x = item & 7;
+        if (TOLFG_VARIANT(a) & (1 << 16)) x ^= 1;              // probes (stamped build): which XCD walks which eighth
+        if (TOLFG_VARIANT(a) & (1 << 17)) x = (x + 4) & 7;
+        if (TOLFG_VARIANT(a) & (1 << 18)) x = (x + 2) & 7;
+        item = x * a.xcd_chunk + (item >> 3);
+    }
+    if (item >= total_tiles(a)) return;            // the grid may be rounded up to 8 * xcd_chunk
+    if (a.stagger) {
+        // A launch whose waves are all resident from the start (outputs within the cache, no cap) would run them in
+        // step: every wave loads, then every wave computes -- four per SIMD, interleaved, so that none is done before
+        // all are -- and only then does the first store leave.  Issue priority by the wave's slot on its SIMD lets one
+        // wave per SIMD run ahead of the next, so the write path starts early and the phases overlap.
+        unsigned hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        switch (hw & 3u) {                         // WAVE_ID, the slot on the SIMD
+        case 0: __builtin_amdgcn_s_setprio(3); break;
+        case 1: __builtin_amdgcn_s_setprio(2); break;
+        case 2: __builtin_amdgcn_s_setprio(1); break;
+        default: break;
         }
-        if (item >= total_tiles(a)) return;            // the grid may be rounded up to 8 * xcd_chunk
-        run_tile<T, MISSION, WIND, VEC, PAT, NT>(a, lds, item, lane);
-        if (a.done) signal_done(a, (int)total_tiles(a), lane == 0);
-        return;
     }
-#ifdef TOLFG_PERSIST_EXPERIMENT
-    unsigned xcc;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    const TileQueues q{a.queues, a.xcd_chunk, (a.xcd_chunk + 3) / 4, (long)a.B * a.tiles};
-    int mine = (int)(xcc & 7) * 4 + (int)((blockIdx.x >> 3) & 3);
-    unsigned pos = q.take(mine, lane);
-    for (long guard = 0; guard <= q.W; guard++) {            // every pass takes a tile or leaves
-        unsigned p = (unsigned)__builtin_amdgcn_readfirstlane((int)pos);
-        while (p >= (unsigned)q.len(mine)) {                 // this chunk is empty: move to one that is not
-            mine = q.other(mine, lane);
-            if (mine < 0) break;
-            p = (unsigned)__builtin_amdgcn_readfirstlane((int)q.take(mine, lane));
-        }
-        if (mine < 0) break;
-        // the next tile's position is asked for once this tile's window is in: on its way while the tile is worked on
-        run_tile<T, MISSION, WIND, VEC, PAT, NT>(a, lds, (int)(q.start(mine) + p), lane, [&]() { pos = q.take(mine, lane); });
-        __syncthreads();                                     // the LDS rows are reused
-    }
-    // the last workgroup to leave puts the heads back to zero for the next launch
-    if (lane == 0) {
-        const unsigned gone = __hip_atomic_fetch_add(q.head + TileQueues::NQ * QUEUE_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (gone == gridDim.x - 1)
-            for (int k = 0; k <= TileQueues::NQ; k++) __hip_atomic_store(q.head + k * QUEUE_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-#endif
+    run_tile<T, MISSION, WIND, VEC, PAT, NT, NP>(a, lds, item, lane);
+    if (a.done) signal_done(a, (int)total_tiles(a), lane == 0);
 }
 
 template <typename T, int MISSION, int PAT>
@@ -1005,7 +1060,7 @@ __global__ __launch_bounds__(8 * TILE) void fg_single_kernel(const FgArgs a)
     }
     T sumT, sumP;
     Publish pub{nullptr, nullptr, 0u};
-    tile_body<T, MISSION, WIND, VEC, PAT, false>(a, lds + (long)w * WAVE_LDS, b * a.tiles + w, lane, sumT, sumP, pub);
+    tile_body<T, MISSION, WIND, VEC, PAT, false, 1>(a, lds + (long)w * WAVE_LDS, b * a.tiles + w, lane, sumT, sumP, pub);
     if (lane == 0) { red[2 * w] = (double)sumT; red[2 * w + 1] = (double)sumP; }
     if (w == 0 && lane < 23) edge[lane] = pre;
     __syncthreads();
@@ -1030,14 +1085,14 @@ __global__ void objectives_kernel(const T *F, long ldf, T *obj, int B)
     if (t < B) obj[t] = F[(long)t * ldf];
 }
 
-template <typename T, int MISSION, int WIND, int PAT>
+template <typename T, int MISSION, int WIND, int PAT, int NP>
 hipError_t launch_vec(const FgArgs &a, int vec, dim3 grid, hipStream_t s, hipEvent_t t0, hipEvent_t t1)
 {
     constexpr int VMAX = 16 / sizeof(T);
     hipError_t e;
     if (a.single) {
         // one workgroup per trajectory, one launch (the callback path)
-        if constexpr (MISSION == MISSION_MIXED) {
+        if constexpr (MISSION == MISSION_MIXED || NP != 1) {
             return hipErrorInvalidValue;           // a mixed batch always takes the tile-per-workgroup path
         } else {
             const unsigned ldsz = (unsigned)(a.tiles * WAVE_LDS * sizeof(T) + 16 * a.tiles + 24 * sizeof(T));
@@ -1066,10 +1121,12 @@ hipError_t launch_vec(const FgArgs &a, int vec, dim3 grid, hipStream_t s, hipEve
         else hipLaunchKernelGGL(kernel, g, dim3(TILE), ldsz, s, a);
     };
     if (vec == VMAX) {
-        if (a.nt_stores) go(fg_kernel<T, MISSION, WIND, VMAX, PAT, true>, grid, lds, t0, fg_end);
-        else             go(fg_kernel<T, MISSION, WIND, VMAX, PAT, false>, grid, lds, t0, fg_end);
-    } else {              // rows of X or F off 16-byte boundaries: scalar window loads and defect stores (plain slab stores)
-        go(fg_kernel<T, MISSION, WIND, 1, PAT, false>, grid, lds, t0, fg_end);
+        if (a.nt_stores) go(fg_kernel<T, MISSION, WIND, VMAX, PAT, true, NP>, grid, lds, t0, fg_end);
+        else             go(fg_kernel<T, MISSION, WIND, VMAX, PAT, false, NP>, grid, lds, t0, fg_end);
+    } else if constexpr (NP == 1) {   // rows of X or F off 16-byte boundaries: scalar window loads and defect stores (plain slab stores)
+        go(fg_kernel<T, MISSION, WIND, 1, PAT, false, 1>, grid, lds, t0, fg_end);
+    } else {
+        return hipErrorInvalidValue;  // two nodes per lane: aligned rows only (the host plans 64-node tiles otherwise)
     }
     e = hipGetLastError();
     if (e != hipSuccess) return e;
@@ -1080,26 +1137,26 @@ hipError_t launch_vec(const FgArgs &a, int vec, dim3 grid, hipStream_t s, hipEve
     return hipSuccess;
 }
 
-template <typename T, int MISSION, int PAT>
+template <typename T, int MISSION, int PAT, int NP>
 hipError_t launch_wind(const FgArgs &a, int wind, int vec, dim3 grid, hipStream_t s, hipEvent_t t0, hipEvent_t t1)
 {
     switch (wind) {
-    case WIND_NONE:  return launch_vec<T, MISSION, WIND_NONE, PAT>(a, vec, grid, s, t0, t1);
-    case WIND_SHEAR: return launch_vec<T, MISSION, WIND_SHEAR, PAT>(a, vec, grid, s, t0, t1);
-    case WIND_TABLE: return launch_vec<T, MISSION, WIND_TABLE, PAT>(a, vec, grid, s, t0, t1);
-    case WIND_GRID:  return launch_vec<T, MISSION, WIND_GRID, PAT>(a, vec, grid, s, t0, t1);
+    case WIND_NONE:  return launch_vec<T, MISSION, WIND_NONE, PAT, NP>(a, vec, grid, s, t0, t1);
+    case WIND_SHEAR: return launch_vec<T, MISSION, WIND_SHEAR, PAT, NP>(a, vec, grid, s, t0, t1);
+    case WIND_TABLE: return launch_vec<T, MISSION, WIND_TABLE, PAT, NP>(a, vec, grid, s, t0, t1);
+    case WIND_GRID:  return launch_vec<T, MISSION, WIND_GRID, PAT, NP>(a, vec, grid, s, t0, t1);
     }
     return hipErrorInvalidValue;
 }
 
-template <typename T, int PAT>
+template <typename T, int PAT, int NP>
 hipError_t launch_mission(const FgArgs &a, int mission, int wind, int vec, dim3 grid, hipStream_t s, hipEvent_t t0,
                           hipEvent_t t1)
 {
     switch (mission) {
-    case MISSION_S10:   return launch_wind<T, MISSION_S10, PAT>(a, wind, vec, grid, s, t0, t1);
-    case MISSION_G7:    return launch_wind<T, MISSION_G7, PAT>(a, wind, vec, grid, s, t0, t1);
-    case MISSION_MIXED: return launch_wind<T, MISSION_MIXED, PAT>(a, wind, vec, grid, s, t0, t1);
+    case MISSION_S10:   return launch_wind<T, MISSION_S10, PAT, NP>(a, wind, vec, grid, s, t0, t1);
+    case MISSION_G7:    return launch_wind<T, MISSION_G7, PAT, NP>(a, wind, vec, grid, s, t0, t1);
+    case MISSION_MIXED: return launch_wind<T, MISSION_MIXED, PAT, NP>(a, wind, vec, grid, s, t0, t1);
     }
     return hipErrorInvalidValue;
 }
@@ -1227,51 +1284,60 @@ __global__ void bounds_kernel(const BoundsArgs a)
 
 }  // namespace
 
-// The evaluation kernels are instantiated per element type in two translation units so that the library builds in
-// parallel (csrc/Makefile: kernels.o with -DTOLFG_TU=0 holds fp64 and everything else, kernels_f32.o with
-// -DTOLFG_TU=1 the fp32 evaluation kernels); a build without TOLFG_TU (tools/fgbench.cpp) holds both.
+// The evaluation kernels are instantiated in three translation units so that the library builds in parallel
+// (csrc/Makefile: kernels.o with -DTOLFG_TU=0 holds fp64 and everything else, kernels_f32.o with -DTOLFG_TU=1 the
+// fp32 evaluation kernels with one node per lane, kernels_f32p.o with -DTOLFG_TU=2 the packed fp32 kernels with two
+// nodes per lane); a build without TOLFG_TU (tools/fgbench.cpp) holds all of them.
 hipError_t launch_fg_f64(const FgArgs &a, int mission, int wind, int vec, dim3 grid, hipStream_t s, hipEvent_t t0, hipEvent_t t1);
 hipError_t launch_fg_f32(const FgArgs &a, int mission, int wind, int vec, dim3 grid, hipStream_t s, hipEvent_t t0, hipEvent_t t1);
+hipError_t launch_fg_f32p(const FgArgs &a, int mission, int wind, int vec, dim3 grid, hipStream_t s, hipEvent_t t0, hipEvent_t t1);
 
 #if !defined(TOLFG_TU) || TOLFG_TU == 1
 hipError_t launch_fg_f32(const FgArgs &a, int mission, int wind, int vec, dim3 grid, hipStream_t s, hipEvent_t t0, hipEvent_t t1)
 {
-    return a.pattern == PATTERN_COMPACT ? launch_mission<float, PATTERN_COMPACT>(a, mission, wind, vec, grid, s, t0, t1)
-                                        : launch_mission<float, PATTERN_REFERENCE>(a, mission, wind, vec, grid, s, t0, t1);
+    return a.pattern == PATTERN_COMPACT ? launch_mission<float, PATTERN_COMPACT, 1>(a, mission, wind, vec, grid, s, t0, t1)
+                                        : launch_mission<float, PATTERN_REFERENCE, 1>(a, mission, wind, vec, grid, s, t0, t1);
+}
+#endif
+
+#if !defined(TOLFG_TU) || TOLFG_TU == 2
+hipError_t launch_fg_f32p(const FgArgs &a, int mission, int wind, int vec, dim3 grid, hipStream_t s, hipEvent_t t0, hipEvent_t t1)
+{
+    return a.pattern == PATTERN_COMPACT ? launch_mission<float, PATTERN_COMPACT, 2>(a, mission, wind, vec, grid, s, t0, t1)
+                                        : launch_mission<float, PATTERN_REFERENCE, 2>(a, mission, wind, vec, grid, s, t0, t1);
 }
 #endif
 
 #if !defined(TOLFG_TU) || TOLFG_TU == 0
 hipError_t launch_fg_f64(const FgArgs &a, int mission, int wind, int vec, dim3 grid, hipStream_t s, hipEvent_t t0, hipEvent_t t1)
 {
-    return a.pattern == PATTERN_COMPACT ? launch_mission<double, PATTERN_COMPACT>(a, mission, wind, vec, grid, s, t0, t1)
-                                        : launch_mission<double, PATTERN_REFERENCE>(a, mission, wind, vec, grid, s, t0, t1);
+    return a.pattern == PATTERN_COMPACT ? launch_mission<double, PATTERN_COMPACT, 1>(a, mission, wind, vec, grid, s, t0, t1)
+                                        : launch_mission<double, PATTERN_REFERENCE, 1>(a, mission, wind, vec, grid, s, t0, t1);
 }
 
 hipError_t launch_fg(const FgArgs &a, int mission, int wind, int dtype, int vec, hipStream_t s, hipEvent_t t0,
                      hipEvent_t t1)
 {
     if (a.B <= 0) return hipSuccess;
-    // the tiling must be one plan_tiles() can produce: nt a multiple of 4 in [4, 64], tiles = ceil(N/nt)
-    if (a.N < 1 || a.nt < 4 || a.nt > TILE || (a.nt & 3) || a.tiles != (a.N + a.nt - 1) / a.nt || !a.partial)
+    // the tiling must be one plan_tiles() can produce: nt a multiple of 4 in [4, 64], tiles = ceil(N/nt); fp32 tiles of
+    // more than 64 (up to 128) nodes select the packed kernels, two nodes per lane
+    const bool packed = dtype == 1 && a.nt > TILE;
+    if (a.N < 1 || a.nt < 4 || a.nt > (dtype == 1 ? 2 * TILE : TILE) || (a.nt & 3) || a.tiles != (a.N + a.nt - 1) / a.nt || !a.partial)
         return hipErrorInvalidValue;
+    if (packed && (a.single || vec != 4)) return hipErrorInvalidValue;
     if ((a.fused || a.done) && !a.counter) return hipErrorInvalidValue;
     if (a.done && !a.fused && !a.single) return hipErrorInvalidValue;     // finalize_kernel would still be running
     if (a.tail_count < 0 || a.tail_count > a.B) return hipErrorInvalidValue;
-    if (a.tail_count > 0 && (a.single || a.persist || a.tail_nt < 4 || a.tail_nt > a.nt || (a.tail_nt & 3) ||
+    if (a.tail_count > 0 && (a.single || a.tail_nt < 4 || a.tail_nt > a.nt || (a.tail_nt & 3) ||
                               a.tail_tiles != (a.N + a.tail_nt - 1) / a.tail_nt))
         return hipErrorInvalidValue;
     const long W = (long)(a.B - a.tail_count) * a.tiles + (long)a.tail_count * a.tail_tiles;
     if (W > 0x7ffffff0L) return hipErrorInvalidValue;
     if (a.xcd_chunk < 0 || a.xcd_chunk > (int)((W + 7) / 8)) return hipErrorInvalidValue;
-#ifdef TOLFG_PERSIST_EXPERIMENT
-    if (a.persist && (a.xcd_chunk <= 0 || a.persist_groups < 1 || a.done || !a.queues)) return hipErrorInvalidValue;
-#else
-    if (a.persist) return hipErrorInvalidValue;            // the persistent form is not part of the product build
-#endif
     const long covered = 8L * a.xcd_chunk;
-    const dim3 grid((unsigned)(a.persist ? a.persist_groups : (covered > W ? covered : W)));
-    return dtype == 0 ? launch_fg_f64(a, mission, wind, vec, grid, s, t0, t1) : launch_fg_f32(a, mission, wind, vec, grid, s, t0, t1);
+    const dim3 grid((unsigned)(covered > W ? covered : W));
+    if (dtype == 0) return launch_fg_f64(a, mission, wind, vec, grid, s, t0, t1);
+    return packed ? launch_fg_f32p(a, mission, wind, vec, grid, s, t0, t1) : launch_fg_f32(a, mission, wind, vec, grid, s, t0, t1);
 }
 
 hipError_t launch_objectives(const void *F, long ldf, void *obj, int B, int dtype, hipStream_t s)
@@ -1316,7 +1382,7 @@ hipError_t launch_bounds(const BoundsArgs &a, int dtype, hipStream_t s)
 int fg_lds_bytes(int dtype, int nt)
 {
     // a spare row and nt rows of RS elements (the x window, 11*nt + 10 elements at most, is staged in the same space first)
-    const int rows = nt > 0 && nt < TILE ? nt : TILE;
+    const int rows = nt > 0 && nt <= 2 * TILE ? nt : TILE;
     return (((rows + 1) * RS * (dtype == 0 ? 8 : 4)) + 15) & ~15;
 }
 

@@ -112,6 +112,7 @@ batch::batch(const std::string &mission, const std::string &root, const std::vec
     if (const char *e = std::getenv("TOLFG_FUSED")) fused_forced_ = std::atoi(e) != 0;
     if (const char *e = std::getenv("TOLFG_NT_STORES")) nt_forced_ = std::atoi(e) != 0;
     if (const char *e = std::getenv("TOLFG_XCD")) xcd_forced_ = std::atoi(e) != 0;
+    if (const char *e = std::getenv("TOLFG_STAGGER")) stagger_forced_ = std::atoi(e) != 0;
     if (const char *e = std::getenv("TOLFG_TAIL")) {        // "count:nt", count 0 = no tail
         tail_forced_ = std::atoi(e);
         if (const char *c = std::strchr(e, ':')) tail_nt_forced_ = std::atoi(c + 1);
@@ -267,8 +268,15 @@ void batch::eval(int B, const void *dX, long ldx, void *dF, long ldf, void *dG, 
     static const bool no_single = std::getenv("TOLFG_NO_SINGLE_LAUNCH") != nullptr;
     a.single = (!no_single && B <= 8 && a.N <= 256 && mission_ != MISSION_MIXED) ? 1 : 0;
     const double out_bytes = (double)elem_size() * B * ((needF ? sz_.neF : 0) + (needG ? sz_.neG : 0));
-    const LaunchPlan lp = plan_launch(out_bytes, dtype_, a.pattern);
-    plan_tiles(a.N, dtype_, a.single ? 0 : (tile_nodes_forced_ > 0 ? tile_nodes_forced_ : lp.max_nt), &a.tiles, &a.nt);
+    // 16-byte window loads and defect stores need the rows of X and F on 16-byte boundaries; the slab stream
+    // copes with any position of G (the waves shift their streams)
+    const int vmax = dtype_ == TOLFG_F64 ? 2 : 4;
+    const bool aligned = (reinterpret_cast<uintptr_t>(dX) % 16 == 0) && (ldx % vmax == 0) &&
+                         (!needF || ((reinterpret_cast<uintptr_t>(dF) % 16 == 0) && (ldf % vmax == 0)));
+    const LaunchPlan lp = plan_launch(LaunchShape{B, a.N, dtype_, a.pattern, mission_, aligned ? 1 : 0, out_bytes});
+    int max_nt = a.single ? 0 : (tile_nodes_forced_ > 0 ? tile_nodes_forced_ : lp.max_nt);
+    if (!aligned && max_nt > 64) max_nt = 64;          // two nodes per lane (fp32 tiles beyond 64 nodes) need 16-byte rows
+    plan_tiles(a.N, dtype_, max_nt, &a.tiles, &a.nt);
     // finer tiles for the trajectories the launch reaches last (FgArgs::tail_count)
     a.tail_count = a.tail_tiles = a.tail_nt = 0;
     const int tail_count = a.single ? 0 : std::min(B, tail_forced_ >= 0 ? tail_forced_ : lp.tail_count);
@@ -312,15 +320,11 @@ void batch::eval(int B, const void *dX, long ldx, void *dF, long ldf, void *dG, 
     a.done = done; a.done_seq = done_seq;
     a.waves_per_cu = waves_forced_ ? waves_per_cu_ : lp.waves_per_cu;
     a.nt_stores = nt_forced_ >= 0 ? nt_forced_ : lp.nt_stores;
+    a.stagger = (stagger_forced_ >= 0 ? stagger_forced_ : lp.stagger) && !a.single ? 1 : 0;
     a.xcd_chunk = ((xcd_forced_ >= 0 ? xcd_forced_ : lp.xcd) && !a.single) ? (int)(a.tail_count ? body / 8 : (W + 7) / 8) : 0;
     a.X = dX; a.ldx = ldx; a.F = dF; a.ldf = ldf; a.G = dG; a.ldg = ldg;
     a.wind = dWind; a.traj = d_traj_;
     a.B = B; a.needF = needF ? 1 : 0; a.needG = needG ? 1 : 0;
-    // 16-byte window loads and defect stores need the rows of X and F on 16-byte boundaries; the slab stream
-    // copes with any position of G (the waves shift their streams)
-    const int vmax = dtype_ == TOLFG_F64 ? 2 : 4;
-    const bool aligned = (reinterpret_cast<uintptr_t>(dX) % 16 == 0) && (ldx % vmax == 0) &&
-                         (!needF || ((reinterpret_cast<uintptr_t>(dF) % 16 == 0) && (ldf % vmax == 0)));
     const int vec = aligned ? vmax : 1;
     hipEvent_t t0 = nullptr, t1 = nullptr;
     if (timing_) {                 // HIP events on the launch stream, around the whole evaluation

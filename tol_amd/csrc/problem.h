@@ -103,6 +103,7 @@ private:
     bool partial_dirty_ = false;        // the partial slots hold a two-launch evaluation's sums (not "empty")
     int tail_forced_ = -1, tail_nt_forced_ = 0;   // TOLFG_TAIL=count:nt overrides the finer-tiled tail (measurements)
     int xcd_forced_ = -1;               // TOLFG_XCD=0/1 overrides the tile order (measurements)
+    int stagger_forced_ = -1;           // TOLFG_STAGGER=0/1 overrides the issue-priority stagger (measurements)
     int ntraj_ = 0, cap_ = 0;
     bool uploaded_ = false;
     TrajDev *d_traj_ = nullptr;

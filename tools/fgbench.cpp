@@ -4,7 +4,7 @@
 // a list of launch configurations back to back on one synthetic S10 or G7 batch, so that tile size,
 // waves-per-CU cap and the fused/unfused finalize can be compared inside ONE gpurun call:
 //
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o tools/bin/fgbench tools/fgbench.cpp      (add -DTOLFG_PERSIST_EXPERIMENT for persist=)
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o tools/bin/fgbench tools/fgbench.cpp      
 //   tools/bin/fgbench [reps=N] [xbuf=K] [nt=0|1] [xcd=0|1] [pat=0|1] B,N,max_nt,cap,fused[,mission[,dtype]] ...
 //
 // Every configuration is first checked against the reference configuration of its shape
@@ -34,6 +34,9 @@ struct Shape {
 
 static long g_goff = 0;             // goff=: G starts this many elements into its allocation (alignment experiments)
 static long g_ldg_pad = 0;          // ldgpad=: extra elements between the rows of G (row-stride experiments)
+static int g_stagger = 0;           // stagger=: FgArgs::stagger
+static int g_variant = 0;           // variant=: ablation switches of a -DTOLFG_ABLATE build (256 no arithmetic, 512 no defect stores,
+                                    // 1024 no objective-gradient stores, 2048 no slab stream, 4096 no x window); results are then wrong
 Shape make_shape(int B, int N, int mission, int dtype)
 {
     Shape s{};
@@ -54,16 +57,16 @@ struct Buffers {
     void *dF = nullptr, *dG = nullptr, *dF2 = nullptr, *dG2 = nullptr;
     tolfg::TrajDev *dT = nullptr;
     double *dP = nullptr;
-    unsigned *dC = nullptr, *dQ = nullptr;
+    unsigned *dC = nullptr;
     long capW = 0, poll_ready = -1;
-    int nt = 1, xcd = 0, pat = 0, persist = 0, xcdpct = 100, tail_count = 0, tail_nt = 16;
+    int nt = 1, xcd = 0, pat = 0, xcdpct = 100, tail_count = 0, tail_nt = 16;
     size_t es() const { return sh.dtype == 0 ? 8 : 4; }
     void release()
     {
         for (void *p : dX) (void)hipFree(p);
         dX.clear();
-        for (void *p : {dF, dG, dF2, dG2, (void *)dT, (void *)dP, (void *)dC, (void *)dQ}) if (p) (void)hipFree(p);
-        dF = dG = dF2 = dG2 = nullptr; dT = nullptr; dP = nullptr; dC = nullptr; dQ = nullptr; capW = 0; poll_ready = -1;
+        for (void *p : {dF, dG, dF2, dG2, (void *)dT, (void *)dP, (void *)dC}) if (p) (void)hipFree(p);
+        dF = dG = dF2 = dG2 = nullptr; dT = nullptr; dP = nullptr; dC = nullptr; capW = 0; poll_ready = -1;
     }
 };
 
@@ -113,8 +116,6 @@ void fill(Buffers &bf, const Shape &sh, int xbuf)
     CK(hipMalloc(&bf.dT, sizeof(tolfg::TrajDev) * sh.B));
     CK(hipMalloc(&bf.dC, sizeof(unsigned) * (sh.B + 1)));
     CK(hipMemset(bf.dC, 0, sizeof(unsigned) * (sh.B + 1)));
-    CK(hipMalloc(&bf.dQ, sizeof(unsigned) * tolfg::QUEUE_WORDS));
-    CK(hipMemset(bf.dQ, 0, sizeof(unsigned) * tolfg::QUEUE_WORDS));
     CK(hipMemcpy(bf.dT, tr.data(), sizeof(tolfg::TrajDev) * sh.B, hipMemcpyHostToDevice));
 }
 
@@ -125,7 +126,7 @@ tolfg::FgArgs make_args(Buffers &bf, int max_nt, int cap, int fused, int xi, voi
     a.X = bf.dX[xi % bf.dX.size()]; a.ldx = sh.ldx; a.F = F; a.ldf = sh.ldf; a.G = static_cast<char *>(G) + g_goff * (sh.dtype == 0 ? 8 : 4); a.ldg = sh.ldg;
     a.wind = nullptr; a.traj = bf.dT; a.B = sh.B; a.N = sh.N; a.c0[0] = 3 * sh.N + 4; a.c0[1] = sh.N + 6;
     tolfg::plan_tiles(sh.N, sh.dtype, max_nt, &a.tiles, &a.nt);
-    if (bf.tail_count > 0 && !bf.persist) {                 // finer tiles for the trajectories reached last
+    if (bf.tail_count > 0) {                 // finer tiles for the trajectories reached last
         a.tail_count = bf.tail_count < sh.B ? bf.tail_count : sh.B;
         tolfg::plan_tiles(sh.N, sh.dtype, bf.tail_nt < a.nt ? bf.tail_nt : a.nt, &a.tail_tiles, &a.tail_nt);
     }
@@ -136,9 +137,8 @@ tolfg::FgArgs make_args(Buffers &bf, int max_nt, int cap, int fused, int xi, voi
         CK(hipMalloc(&bf.dP, sizeof(double) * 2 * W));
         bf.capW = W;
     }
-    a.partial = bf.dP; a.counter = bf.dC; a.queues = bf.dQ; a.fused = fused; a.single = 0; a.obj = nullptr;
-    a.nt_stores = bf.nt; a.xcd_chunk = (bf.xcd || bf.persist) ? (int)((bf.persist ? W + 7 : (a.tail_count ? body : W) * bf.xcdpct / 100) / 8) : 0;
-    a.persist = (bf.persist > 0 && W > 256L * bf.persist) ? 1 : 0; a.persist_groups = 256 * bf.persist;
+    a.partial = bf.dP; a.counter = bf.dC; a.fused = fused; a.single = 0; a.obj = nullptr;
+    a.nt_stores = bf.nt; a.xcd_chunk = bf.xcd ? (int)(((a.tail_count ? body : W) * bf.xcdpct / 100) / 8) : 0;
     if (fused && bf.poll_ready != W) {   // slots start empty; the unfused path leaves values behind
         CK(hipMemsetD32(reinterpret_cast<hipDeviceptr_t>(bf.dP), tolfg::kEmptySlotWord, 4 * (size_t)W));
         CK(hipDeviceSynchronize());
@@ -146,7 +146,10 @@ tolfg::FgArgs make_args(Buffers &bf, int max_nt, int cap, int fused, int xi, voi
     } else if (!fused) {
         bf.poll_ready = -1;
     }
-    a.needF = 1; a.needG = 1; a.pattern = bf.pat; a.waves_per_cu = cap;
+    a.needF = 1; a.needG = 1; a.pattern = bf.pat; a.waves_per_cu = cap; a.stagger = g_stagger;
+#ifdef TOLFG_ABLATE
+    a.variant = g_variant;
+#endif
     if (bf.pat == tolfg::PATTERN_COMPACT) { a.c0[0] = 3 * sh.N + 4; a.c0[1] = sh.N + 6; }
     a.kT[0] = 0.3; a.kp[0] = 8; a.kv[0] = 0; a.kdt[0] = 1;
     a.kT[1] = 100; a.kp[1] = 0.7; a.kv[1] = 0.4; a.kdt[1] = 0;
@@ -154,7 +157,7 @@ tolfg::FgArgs make_args(Buffers &bf, int max_nt, int cap, int fused, int xi, voi
     return a;
 }
 
-long compare(const Buffers &bf)
+long compare(const Buffers &bf, bool approx = false)
 {
     const Shape &sh = bf.sh;
     const size_t es = bf.es();
@@ -169,7 +172,27 @@ long compare(const Buffers &bf)
         double o1, o2;
         if (es == 8) { o1 = *(const double *)f1; o2 = *(const double *)f2; }
         else { o1 = *(const float *)f1; o2 = *(const float *)f2; }
-        if (!(std::fabs(o1 - o2) <= (es == 8 ? 1e-13 : 2e-6) * (1 + std::fabs(o1)))) bad++;
+        if (!(std::fabs(o1 - o2) <= (es == 8 ? 1e-13 : 2e-6) * (1 + std::fabs(o1)))) {
+            static int shown_obj = 0;
+            if (shown_obj++ < 4) fprintf(stderr, "  objective mismatch b=%d: %.17g vs %.17g\n", b, o1, o2);
+            bad++;
+        }
+        if (approx) {      // packed fp32 kernels: own sin/cos and reciprocals, so a tolerance instead of bit equality
+            static int shown = 0;
+            auto close = [&](const char *what, const char *p, const char *q, long n) {
+                for (long i = 0; i < n; i++) {
+                    const float u = ((const float *)p)[i], v = ((const float *)q)[i];
+                    if (std::memcmp(&u, &v, 4) != 0 && !(std::fabs(u - v) <= 2e-5f * (1 + std::fabs(v)))) {
+                        if (shown++ < 12) fprintf(stderr, "  mismatch %s[b=%d][%ld]: %.9g vs reference configuration %.9g\n", what, b, i, u, v);
+                        return false;
+                    }
+                }
+                return true;
+            };
+            if (!close("F", f1 + es, f2 + es, sh.neF - 1)) bad++;
+            if (!close("G", &G1[es * b * sh.ldg], &G2[es * b * sh.ldg], sh.neG)) bad++;
+            continue;
+        }
         if (std::memcmp(f1 + es, f2 + es, es * (sh.neF - 1)) != 0) bad++;
         if (std::memcmp(&G1[es * b * sh.ldg], &G2[es * b * sh.ldg], es * sh.neG) != 0) bad++;
     }
@@ -193,10 +216,11 @@ int main(int argc, char **argv)
         if (!strncmp(argv[i], "nt=", 3)) { bf.nt = atoi(argv[i] + 3); continue; }
         if (!strncmp(argv[i], "xcd=", 4)) { bf.xcd = atoi(argv[i] + 4); continue; }
         if (!strncmp(argv[i], "xcdpct=", 7)) { bf.xcdpct = atoi(argv[i] + 7); continue; }       // share of the tiles dealt XCD-contiguously
+        if (!strncmp(argv[i], "stagger=", 8)) { g_stagger = atoi(argv[i] + 8); continue; }
+        if (!strncmp(argv[i], "variant=", 8)) { g_variant = atoi(argv[i] + 8); continue; }
         if (!strncmp(argv[i], "goff=", 5)) { g_goff = atol(argv[i] + 5); bf.release(); bf.sh = Shape{}; continue; }
         if (!strncmp(argv[i], "ldgpad=", 7)) { g_ldg_pad = atol(argv[i] + 7); bf.release(); bf.sh = Shape{}; continue; }
         if (!strncmp(argv[i], "tail=", 5)) { bf.tail_count = atoi(argv[i] + 5); const char *c = strchr(argv[i], ':'); if (c) bf.tail_nt = atoi(c + 1); continue; }   // tail=count:nt
-        if (!strncmp(argv[i], "persist=", 8)) { bf.persist = atoi(argv[i] + 8); continue; }     // workgroups per CU, 0 = off
         if (!strncmp(argv[i], "pat=", 4)) { bf.pat = atoi(argv[i] + 4); bf.release(); bf.sh = Shape{}; continue; }
         int v[7] = {4096, 200, 64, 0, 0, 0, 0};
         int nv = 0;
@@ -219,7 +243,8 @@ int main(int argc, char **argv)
         CK(hipMemsetAsync(bf.dG, 0xff, bf.es() * sh.B * sh.ldg, st));
         CK(tolfg::launch_fg(a, sh.mission, tolfg::WIND_SHEAR, sh.dtype, vec, st));
         CK(hipStreamSynchronize(st));
-        const long bad = compare(bf);
+        const bool approx = sh.dtype == 1 && a.nt > 64;
+        const long bad = compare(bf, approx);
         for (int w = 0; w < 5; w++) {
             tolfg::FgArgs aw = make_args(bf, v[2], v[3], v[4], w, bf.dF, bf.dG);
             CK(tolfg::launch_fg(aw, sh.mission, tolfg::WIND_SHEAR, sh.dtype, vec, st));
@@ -254,7 +279,7 @@ int main(int argc, char **argv)
         CK(hipMemsetAsync(bf.dG, 0xff, bf.es() * sh.B * sh.ldg, st));
         CK(tolfg::launch_fg(a, sh.mission, tolfg::WIND_SHEAR, sh.dtype, vec, st));
         CK(hipStreamSynchronize(st));
-        const long bad2 = compare(bf);
+        const long bad2 = compare(bf, approx);
         const long neG_eff = bf.pat == tolfg::PATTERN_COMPACT ? sh.c0 + 46L * sh.N + (sh.mission == tolfg::MISSION_G7 ? 30 : 22) : sh.neG;
         const double bytes = (double)bf.es() * sh.B * ((double)sh.n + sh.neF + neG_eff);
         const double us = 1e3 * ms / reps;
@@ -262,7 +287,7 @@ int main(int argc, char **argv)
         if (a.tail_count) snprintf(tailtxt, sizeof tailtxt, " tail %d x (%d x %d)", a.tail_count, a.tail_tiles, a.tail_nt);
         printf("| %d | %d | %s | %s | %d -> %d x %d | %d | %d%s%s%s | %.2f | %.2f | %.2f | %.0f | %.1f | %s |\n", sh.B, sh.N,
                sh.mission == 0 ? "S10" : (sh.mission == 1 ? "G7" : "mixed"), sh.dtype == 0 ? "f64" : "f32", v[2], a.tiles, a.nt, v[3], v[4],
-               bf.nt ? " nt" : " plain", a.persist ? " persist" : (bf.xcd ? (bf.xcdpct == 100 ? " xcd" : " xcd-part") : ""), tailtxt, us, kern_us, us_plain,
+               bf.nt ? " nt" : " plain", bf.xcd ? (bf.xcdpct == 100 ? " xcd" : " xcd-part") : "", tailtxt, us, kern_us, us_plain,
                bytes / (1e3 * us_plain), 100.0 * bytes / (1e3 * us_plain) / 8000.0, (bad || bad2) ? "MISMATCH" : "ok");
         fflush(stdout);
     }
