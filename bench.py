@@ -7,16 +7,20 @@ plus the gather of the per-trajectory objectives (on N > 1 GPUs that gather is o
 over xGMI, issued asynchronously so it overlaps the next step's launch).  Inputs are resident in HBM
 before the timed region starts.
 
-Headline workload (BASELINE.json configs[1] batched as configs[3] prescribes): problemS10,
-tempest.param, ts = 200 collocation nodes, fp64; per-trajectory linear-shear wind Vref~U(0,5),
-href~U(5,20), start offset (xi,yi,zi)~U(-50,50)^2 x U(-100,-20), x = x0(start) + 5 % noise, seed
-1000 + global trajectory index.  Weak scaling by default
-(--batch trajectories per GPU); --global-batch G fixes the total instead (strong scaling: rank r
-owns shard_bounds(G, r, N)), which is how configs[3] (G = 1024) and configs[4] (G = 8192) are run
-as stated.
+Headline workload = the largest BASELINE config that fits one GPU, configs[4]: a mixed batch of
+problemG7 + problemS10 trajectories (mission = b mod 2), all five aircraft .param files (b mod 5),
+ts = 200 collocation nodes, fp64, 8192 trajectories per GPU; per-trajectory linear-shear wind
+Vref~U(0,5), href~U(5,20), start offset (xi,yi,zi)~U(-50,50)^2 x U(-100,-20), x = x0(start) + 5 %
+noise, seed 1000 + global trajectory index.  Weak scaling by
+default (--batch trajectories per GPU); --global-batch G fixes the total instead (strong scaling:
+rank r owns shard_bounds(G, r, N)).
 
-On one GPU the JSON line also carries `configs`: one measured record per BASELINE config
-(device-resident evaluation and, for the single-trajectory configs, the host->host SNOPT callback).
+The JSON line also carries `configs`: one measured record per BASELINE config.  On any number of
+GPUs: configs[3] (global batch 1024, S10) and configs[4] (global batch 8192 mixed, fp64 and fp32) AS
+STATED, i.e. strong scaling -- every rank evaluates its shard and the objectives are all-gathered,
+inside the same process group after the headline.  On one GPU also the single-trajectory configs
+(device-resident and through the host->host SNOPT callback), the shares one of 8 GPUs gets, and the
+side records (the round-2 headline shape S10/4096, compact pattern, two streams).
 
 Launch: `python bench.py --gpus 1 ...` or, for N > 1,
 `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P
@@ -119,47 +123,55 @@ def device_record(tol_amd, torch, cfg, workload, mission, aircraft, ts, B, dtype
 
 
 def cpu_baseline(args, seconds):
-    """Time the oracle (kind 'port') on this box's host cores; rank 0, N = 1 only.
+    """Time the oracle (kind 'port') on this box's host cores; rank 0, N = 1 only, on a bounded sample of the headline
+    workload: one trajectory per (mission, air-frame) class of the batch, evaluated round-robin.
     Main figure: ONE core, the reference's own evaluation order (one Jacobian entry per call, its
     whole row rebuilt each time: src/problem.cpp:782-806,1035-1208), -O2.  Extras: the same at -O0
     (the reference's shipped build config, .cproject:30-31) and the fused per-node form on all cores."""
     from oracle import oracle as O
-    o = O.Problem(args.mission, args.aircraft, N=args.ts)
-    x = O.perturbed(o, 7)
-    disp = o.dispatch()
+    if args.mission == "mixed":
+        classes = [(("S10", "G7")[g % 2], AIRCRAFT5[g % 5]) for g in range(10)]
+    else:
+        classes = [(args.mission, args.aircraft)]
+    probs = [O.Problem(m, a, N=args.ts, radius_goal=100.0 if m == "S10" else 0.0) for m, a in classes]
+    xs = [O.perturbed(o, 7 + i) for i, o in enumerate(probs)]
+    disp = [o.dispatch() for o in probs]
     out = {}
     for opt in ("O2", "O0"):
-        o.eval_entrywise(x, opt=opt, dispatch=disp)
+        probs[0].eval_entrywise(xs[0], opt=opt, dispatch=disp[0])
         n, t0 = 0, time.perf_counter()
         budget = seconds if opt == "O2" else seconds / 3
         while time.perf_counter() - t0 < budget:
-            o.eval_entrywise(x, opt=opt, dispatch=disp)
+            k = n % len(probs)
+            probs[k].eval_entrywise(xs[k], opt=opt, dispatch=disp[k])
             n += 1
         dt = time.perf_counter() - t0
         out[opt] = (n * args.ts / dt, n, dt)
     # fused per-node form on one core (BASELINE.md section 4, variant b)
-    o.eval(x)
+    probs[0].eval(xs[0])
     n1, t0 = 0, time.perf_counter()
     while time.perf_counter() - t0 < seconds / 6:
-        o.eval(x)
+        k = n1 % len(probs)
+        probs[k].eval(xs[k])
         n1 += 1
     fused1 = n1 * args.ts / (time.perf_counter() - t0)
     # fused per-node form, all host cores, OpenMP over trajectories
     # worker pool sized to the GPU box's CPU share (16 per GPU), not to every core the host shows
     cores = int(os.environ.get("TOLFG_CPU_THREADS", min(len(os.sched_getaffinity(0)), 16)))
-    Bc = max(cores * 8, 64)
-    probs = [o] * Bc
-    X = np.stack([O.perturbed(o, 100 + i) for i in range(Bc)])
-    O.eval_batch(probs, X, nthreads=cores)
+    Bc = max(cores * 8, 64) // len(probs) * len(probs)
+    many = [probs[i % len(probs)] for i in range(Bc)]
+    X = np.stack([O.perturbed(many[i], 100 + i) for i in range(Bc)])
+    O.eval_batch(many, X, nthreads=cores)
     n, t0 = 0, time.perf_counter()
     while time.perf_counter() - t0 < seconds / 2:
-        _, _, used = O.eval_batch(probs, X, nthreads=cores)
+        _, _, used = O.eval_batch(many, X, nthreads=cores)
         n += 1
     dt = time.perf_counter() - t0
     fused = n * Bc * args.ts / dt
+    what = "+".join(sorted({m for m, _ in classes})) + "/" + ("five air-frames" if len(classes) > 1 else args.aircraft)
     base = {"value": out["O2"][0], "unit": "node-evals/s", "cores": 1, "kind": "port",
-            "sample": f"{out['O2'][1]} evaluations of one {args.mission}/{args.aircraft}/ts={args.ts} trajectory "
-                      f"in {out['O2'][2]:.1f} s, reference evaluation order (entry-wise Jacobian), gcc -O2",
+            "sample": f"{out['O2'][1]} evaluations over {len(probs)} {what}/ts={args.ts} trajectories (one per mission x air-frame class of "
+                      f"the batch, round-robin) in {out['O2'][2]:.1f} s, reference evaluation order (entry-wise Jacobian), gcc -O2",
             "value_O0": out["O0"][0],
             "fused_one_core": {"value": fused1, "cores": 1, "sample": f"{n1} evaluations, per-node fused form, gcc -O2"},
             "fused_all_cores": {"value": fused, "cores": used, "sample": f"{n} x {Bc} trajectories, per-node fused form, OpenMP"}}
@@ -238,39 +250,193 @@ def two_streams_record(tol_amd, torch, args, B, device, steps=100):
             "algorithmic_GBs": alg * 2 * steps / wall / 1e9, "frac_of_hbm_peak": alg * 2 * steps / wall / 1e9 / HBM_PEAK_GBS}
 
 
-def config_records(tol_amd, torch, device):
-    """BASELINE.json configs, each on ONE GPU at its own sizes.  configs[0] is the CPU/SNOPT
-    plumbing case (tests/test_cpp_plumbing.py); configs[3] and [4] also at the share one of 8 GPUs gets."""
+def single_gpu_records(tol_amd, torch, device):
+    """BASELINE.json configs that are one-GPU cases, each at its own sizes: the single-trajectory
+    configs device-resident and through the callback, and the shares one of 8 GPUs gets of configs[3] and [4].
+    configs[0] is the CPU/SNOPT plumbing case (tests/test_cpp_plumbing.py)."""
     recs = []
     recs.append(device_record(tol_amd, torch, 1, "configs[1] problemS10/tempest/ts=200, one trajectory", "S10", ("tempest",), 200, 1, "f64", 200, device, 1))
     recs.append(callback_mode(tol_amd, "S10", "tempest", 200, 400, cfg=1))
     recs.append(device_record(tol_amd, torch, 2, "configs[2] problemS10/skywalker/ts=2000, one trajectory", "S10", ("skywalker",), 2000, 1, "f64", 200, device, 1))
     recs.append(callback_mode(tol_amd, "S10", "skywalker", 2000, 200, cfg=2))
-    recs.append(device_record(tol_amd, torch, 3, "configs[3] batch=1024 problemS10 ts=200, randomized wind/IC", "S10", ("tempest",), 200, 1024, "f64", 100, device))
     recs.append(device_record(tol_amd, torch, 3, "configs[3] share of one of 8 GPUs: batch=128", "S10", ("tempest",), 200, 128, "f64", 200, device))
     for dtype in ("f64", "f32"):
-        recs.append(device_record(tol_amd, torch, 4, "configs[4] mixed G7+S10 batch=8192, five air-frames, ts=200, one launch", "mixed", AIRCRAFT5, 200, 8192, dtype, 50, device))
         recs.append(device_record(tol_amd, torch, 4, "configs[4] share of one of 8 GPUs: batch=1024", "mixed", AIRCRAFT5, 200, 1024, dtype, 100, device))
+    return recs
+
+
+class Job:
+    """The process group of this run (one rank per GPU) and the one collective the path has."""
+
+    def __init__(self, torch, dist, world, rank, local, backend):
+        self.torch, self.dist, self.world, self.rank, self.local, self.backend = torch, dist, world, rank, local, backend
+
+    def barrier(self):
+        self.torch.cuda.synchronize()
+        if self.world > 1:
+            if self.backend == "nccl":
+                self.dist.barrier(device_ids=[self.local])
+            else:
+                self.dist.barrier()
+            self.torch.cuda.synchronize()
+
+    def max_over_ranks(self, values):
+        t = self.torch.tensor(values, dtype=self.torch.float64, device="cuda")
+        if self.world > 1:
+            if self.backend == "nccl":
+                self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            else:
+                c = t.cpu()
+                self.dist.all_reduce(c, op=self.dist.ReduceOp.MAX)
+                t = c
+        return [float(v) for v in t]
+
+
+def sharded_run(tol_amd, job, mission, aircraft, ts, dtype, pattern, per_gpu, global_batch, steps, warmup, x_buffers, instrumented=True):
+    """Exactly `steps` steps of one workload over the job's ranks between two barriers.  A step = this rank's shard in ONE
+    launch (F, G and the objectives) + the all-gather of the objectives (N > 1; asynchronous, double-buffered, so it
+    overlaps the next step's launch).  per_gpu > 0: weak scaling, that many trajectories per rank; else global_batch
+    trajectories split by shard_bounds (strong scaling).  Returns the timings as maxima over the ranks."""
+    from tol_amd.distributed import shard_bounds
+    torch, dist, world, rank = job.torch, job.dist, job.world, job.rank
+    if per_gpu > 0:
+        B, first, total, scaling = per_gpu, rank * per_gpu, per_gpu * world, "weak"
+        Bmax = B
+    else:
+        lo, hi = shard_bounds(global_batch, rank, world)
+        B, first, total, scaling = hi - lo, lo, global_batch, "strong"
+        Bmax = shard_bounds(total, 0, world)[1]                     # widest shard (gather buffer)
+    bt = tol_amd.Batch(mission, aircraft, ts=ts, dtype=dtype, device=job.local, pattern=pattern)
+    bt.set_trajectories(make_trajectories(tol_amd, max(B, 1), first, mission, len(aircraft)))
+    dXs, dF, dG = make_inputs(bt, torch, max(B, 1), first, x_buffers)
+    obj = [torch.zeros(Bmax, dtype=dF.dtype, device=dF.device) for _ in range(2)]
+    gdev = dF.device if job.backend == "nccl" else torch.device("cpu")
+    allobj = [torch.empty(Bmax * world, dtype=dF.dtype, device=gdev) for _ in range(2)] if world > 1 else None
+    pending = [None, None]
+
+    def step(i):
+        s = i & 1
+        if world > 1 and pending[s] is not None:
+            pending[s].wait()                      # buffer reuse: the gather of step i-2 must be done
+        if B > 0:
+            bt.eval(dXs[i % len(dXs)], dF, dG, obj=obj[s], B=B)     # the finalizing waves also write the objectives, contiguous
+        if world > 1:
+            src = obj[s] if job.backend == "nccl" else obj[s].cpu()
+            pending[s] = dist.all_gather_into_tensor(allobj[s], src, async_op=True)
+
+    def fence():
+        for s in (0, 1):
+            if pending[s] is not None:
+                pending[s].wait()
+                pending[s] = None
+        job.barrier()
+
+    for i in range(warmup):
+        step(i)
+    fence()
+    # The timed region: exactly `steps` steps between two barriers.  Two HIP events on the launch stream bracket the
+    # launches (before the first, after the last): their distance / steps is the average time per launch, the ~2 us
+    # between dependent launches included -- an upper bound of the kernel's own duration, taken without instrumenting it.
+    bt.set_timing(False)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for i in range(steps):
+        step(i)
+    ev1.record()
+    fence()
+    elapsed = time.perf_counter() - t0
+    kern_ms = ev0.elapsed_time(ev1) / steps
+    last = (steps - 1) & 1
+    assert B == 0 or torch.isfinite(obj[last][:B]).all(), "non-finite objective"
+    if world > 1:      # every rank's shard arrived in place, in global trajectory order
+        mine = obj[last].to(allobj[last].device)
+        assert torch.equal(allobj[last][rank * Bmax:(rank + 1) * Bmax], mine), "gathered objectives are out of order"
+    out = {"B": B, "total": total, "scaling": scaling, "x_buffers": len(dXs)}
+    # the gather alone (N > 1): synchronous all-gathers of the same buffers, nothing else in flight
+    gather_us = 0.0
+    if world > 1:
+        reps = 50
+        src = obj[0] if job.backend == "nccl" else obj[0].cpu()
+        for _ in range(5):
+            dist.all_gather_into_tensor(allobj[0], src)
+        job.barrier()
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            dist.all_gather_into_tensor(allobj[0], src)
+        torch.cuda.synchronize()
+        gather_us = 1e6 * (time.perf_counter() - t1) / reps
+        job.barrier()
+    # Outside the timed region, the same steps again with start / stop events attached to every dispatch (the library's
+    # tolfg_batch_set_timing; rocprofv3 --kernel-trace turns the same dispatch profiling on): per-launch durations, but
+    # each launch then takes 10-16 us longer, part of it inside the reported duration (profiles/r02_event_cost.md).
+    inst_ms = inst_min_ms = inst_step_ms = 0.0
+    if instrumented and B > 0:
+        bt.set_timing(True)
+        t1 = time.perf_counter()
+        for i in range(steps):
+            step(i)
+        fence()
+        inst_step_ms = 1e3 * (time.perf_counter() - t1) / steps
+        nlaunch, inst_ms, inst_min_ms = bt.kernel_time()
+        bt.set_timing(False)
+        assert nlaunch == steps
+    elif instrumented:
+        fence()
+    elapsed, kern_ms, gather_us = job.max_over_ranks([elapsed, kern_ms, gather_us])
+    out.update(elapsed=elapsed, kern_ms=kern_ms, gather_us=gather_us, inst_ms=inst_ms, inst_min_ms=inst_min_ms, inst_step_ms=inst_step_ms,
+               alg_bytes=bt.algorithmic_bytes(B) if B > 0 else 0.0)
+    bt.close()
+    del dXs, dF, dG, obj, allobj
+    torch.cuda.empty_cache()
+    return out
+
+
+def stated_config_records(tol_amd, job, x_buffers):
+    """configs[3] and configs[4] AS STATED in BASELINE.json -- a global batch of 1024 S10 trajectories, a global mixed
+    batch of 8192 in fp64 and fp32 -- sharded over however many GPUs the job has (strong scaling): per step every rank
+    evaluates its shard in one launch and the objectives are all-gathered."""
+    recs = []
+    for cfg, what, mission, aircraft, G, dtype, steps in (
+            (3, "configs[3] batch=1024 problemS10 ts=200, randomized wind/IC", "S10", ("tempest",), 1024, "f64", 200),
+            (4, "configs[4] mixed G7+S10 batch=8192, five air-frames, ts=200", "mixed", AIRCRAFT5, 8192, "f64", 100),
+            (4, "configs[4] mixed G7+S10 batch=8192, five air-frames, ts=200", "mixed", AIRCRAFT5, 8192, "f32", 100)):
+        r = sharded_run(tol_amd, job, mission, aircraft, 200, dtype, "reference", 0, G, steps, 10, x_buffers)
+        if job.rank != 0:
+            continue
+        world = job.world
+        # rank 0's shard is the widest: its bytes bound every rank's; the job moves `total` trajectories per step
+        alg_total = r["alg_bytes"] * G / max(r["B"], 1)
+        recs.append({"config": cfg, "workload": what + (f", global batch sharded over {world} GPUs (strong scaling)" if world > 1 else ", one launch"),
+                     "mode": "device-resident", "batch": G, "batch_per_gpu": r["B"], "n_gpus": world, "ts": 200, "dtype": dtype, "steps": steps,
+                     "ms_per_step": 1e3 * r["elapsed"] / steps, "node_evals_per_s": G * 200 * steps / r["elapsed"],
+                     "eval_us": 1e3 * r["kern_ms"], "eval_us_instrumented": 1e3 * r["inst_ms"], "eval_min_us_instrumented": 1e3 * r["inst_min_ms"],
+                     "gather_us": r["gather_us"], "launches_per_step": 1,
+                     "algorithmic_bytes": alg_total, "achieved_GBs": alg_total / (r["kern_ms"] * 1e-3) / 1e9,
+                     "frac_of_hbm_peak": alg_total / (r["kern_ms"] * 1e-3) / 1e9 / (HBM_PEAK_GBS * world),
+                     "frac_of_hbm_peak_whole_step": alg_total / (r["elapsed"] / steps) / 1e9 / (HBM_PEAK_GBS * world),
+                     "note": "eval_us = slowest rank's time per launch (HIP events on its launch stream); gather_us = one synchronous "
+                             "all-gather of the objectives alone; fractions are of n_gpus x 8 TB/s"})
     return recs
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1000)
-    ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--batch", type=int, default=4096, help="trajectories per GPU (weak scaling)")
+    ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--batch", type=int, default=8192, help="trajectories per GPU (weak scaling)")
     ap.add_argument("--global-batch", type=int, default=0,
-                    help="total trajectories over all GPUs (strong scaling; configs[3]: 1024, configs[4]: 8192 with --mission mixed)")
+                    help="total trajectories over all GPUs instead of --batch per GPU (strong scaling)")
     ap.add_argument("--ts", type=int, default=200)
-    ap.add_argument("--mission", default="S10", choices=["S10", "G7", "mixed"])
-    ap.add_argument("--aircraft", default="tempest", help="air-frame; a mixed batch uses all five")
+    ap.add_argument("--mission", default="mixed", choices=["S10", "G7", "mixed"])
+    ap.add_argument("--aircraft", default="tempest", help="air-frame of a single-mission batch; a mixed batch uses all five")
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the per-BASELINE-config records and side runs")
     ap.add_argument("--x-buffers", type=int, default=4,
-                    help="distinct input batches rotated over the steps; 4 x 72 MB exceed the 256 MiB Infinity "
+                    help="distinct input batches rotated over the steps; 4 x 145 MB exceed the 256 MiB Infinity "
                          "Cache, so every step reads its X from HBM rather than from a cache that kept it")
     ap.add_argument("--pattern", default="reference", choices=["reference", "compact"],
                     help="Jacobian sparsity pattern; the headline metric is quoted on the reference's own pattern")
@@ -282,7 +448,6 @@ def main():
     import torch
     import torch.distributed as dist
     import tol_amd
-    from tol_amd.distributed import shard_bounds
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -318,89 +483,20 @@ def main():
                 os._exit(3)
         else:
             dist.init_process_group("gloo")
+    job = Job(torch, dist, world, rank, local, args.backend)
 
     aircraft = AIRCRAFT5 if args.mission == "mixed" else (args.aircraft,)
-    if args.global_batch > 0:
-        lo, hi = shard_bounds(args.global_batch, rank, world)
-        B, first, total, scaling = hi - lo, lo, args.global_batch, "strong"
-    else:
-        B, first, total, scaling = args.batch, rank * args.batch, args.batch * world, "weak"
-    Bmax = shard_bounds(total, 0, world)[1] if args.global_batch > 0 else B      # widest shard (gather buffer)
-    bt = tol_amd.Batch(args.mission, aircraft, ts=args.ts, dtype=args.dtype, device=local, pattern=args.pattern)
-    bt.set_trajectories(make_trajectories(tol_amd, B, first, args.mission, len(aircraft)))
-    dXs, dF, dG = make_inputs(bt, torch, B, first, args.x_buffers)
-    obj = [torch.zeros(Bmax, dtype=dF.dtype, device=dF.device) for _ in range(2)]
-    gdev = dF.device if args.backend == "nccl" else torch.device("cpu")
-    allobj = [torch.empty(Bmax * world, dtype=dF.dtype, device=gdev) for _ in range(2)] if world > 1 else None
-    pending = [None, None]
-
-    def step(i):
-        s = i & 1
-        if world > 1 and pending[s] is not None:
-            pending[s].wait()                      # buffer reuse: the gather of step i-2 must be done
-        bt.eval(dXs[i % len(dXs)], dF, dG, obj=obj[s], B=B)     # the finalizing waves also write the objectives, contiguous
-        if world > 1:
-            src = obj[s] if args.backend == "nccl" else obj[s].cpu()
-            pending[s] = dist.all_gather_into_tensor(allobj[s], src, async_op=True)
-
-    def fence():
-        for s in (0, 1):
-            if pending[s] is not None:
-                pending[s].wait()
-                pending[s] = None
-        torch.cuda.synchronize()
-        if world > 1:
-            if args.backend == "nccl":
-                dist.barrier(device_ids=[local])
-            else:
-                dist.barrier()
-            torch.cuda.synchronize()
-
-    for i in range(args.warmup):
-        step(i)
-    fence()
-    # The timed region: exactly args.steps steps between two barriers.  Two HIP events on the launch stream bracket the
-    # launches (before the first, after the last): their distance / steps is the average time per launch, the ~2 us
-    # between dependent launches included -- an upper bound of the kernel's own duration, taken without instrumenting it.
-    bt.set_timing(False)
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    for i in range(args.steps):
-        step(i)
-    ev1.record()
-    fence()
-    elapsed = time.perf_counter() - t0
-    kern_ms = ev0.elapsed_time(ev1) / args.steps
-    # Outside the timed region, the same steps again with start / stop events attached to every dispatch (the library's
-    # tolfg_batch_set_timing; rocprofv3 --kernel-trace turns the same dispatch profiling on): per-launch durations, but
-    # each launch then takes 10-16 us longer, part of it inside the reported duration (profiles/r02_event_cost.md).
-    bt.set_timing(True)
-    t1 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    fence()
-    inst_step_ms = 1e3 * (time.perf_counter() - t1) / args.steps
-    nlaunch, inst_ms, inst_min_ms = bt.kernel_time()
-    bt.set_timing(False)
-    assert nlaunch == args.steps
-    el = torch.tensor([elapsed, kern_ms], dtype=torch.float64, device="cuda")
-    if world > 1:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    elapsed, kern_ms = el[0].item(), el[1].item()
-
-    # sanity: the objectives that came back are finite and, on N > 1, every rank's shard arrived in place
-    last = (args.steps - 1) & 1
-    assert torch.isfinite(obj[last][:B]).all(), "non-finite objective"
-    if world > 1:
-        mine = obj[last].to(allobj[last].device)
-        assert torch.equal(allobj[last][rank * Bmax:(rank + 1) * Bmax], mine), "gathered objectives are out of order"
+    r = sharded_run(tol_amd, job, args.mission, aircraft, args.ts, args.dtype, args.pattern,
+                    0 if args.global_batch > 0 else args.batch, args.global_batch, args.steps, args.warmup, args.x_buffers)
+    configs = None
+    if not args.no_configs:
+        configs = stated_config_records(tol_amd, job, args.x_buffers)      # every rank takes part
 
     if rank == 0:
-        nodes_per_step = total * args.ts
-        value = nodes_per_step * args.steps / elapsed
-        alg_bytes = bt.algorithmic_bytes(B)
-        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+        B, total = r["B"], r["total"]
+        value = total * args.ts * args.steps / r["elapsed"]
+        alg_bytes = r["alg_bytes"]
+        achieved = alg_bytes / (r["kern_ms"] * 1e-3) / 1e9
         traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tpath):
@@ -414,50 +510,56 @@ def main():
             except (OSError, ValueError):
                 traffic = None
         backend = "none (single GPU)" if world == 1 else ("rccl" if args.backend == "nccl" else "gloo (host-staged rehearsal)")
+        if args.mission == "mixed":
+            what = (f"BASELINE configs[4]: mixed problemG7 + problemS10 batch (mission = b mod 2), all five aircraft .param files "
+                    f"(b mod 5), ts={args.ts}, {args.dtype}")
+        else:
+            what = f"problem{args.mission}/{'+'.join(aircraft)}.param/ts={args.ts}, {args.dtype} (BASELINE configs[1] batched as configs[3] prescribes)"
         line = {
             "metric": "collocation-node F/G+Jacobian evals/sec",
             "value": value, "unit": "node-evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": scaling,
+            "ms_per_step": 1e3 * r["elapsed"] / args.steps, "higher_is_better": True, "scaling": r["scaling"],
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic", "backend": backend,
-            "config": {"workload": f"problem{args.mission}/{'+'.join(aircraft)}.param/ts={args.ts} (BASELINE configs[1]) as a "
-                                   f"device-resident batch of {B} trajectories per GPU with randomized shear wind and "
-                                   f"start offsets (configs[3] recipe); one F+G launch + objective gather per step",
+            "config": {"workload": what + f": a device-resident batch of {B} trajectories per GPU with randomized shear wind and "
+                                          f"start offsets; one F+G launch + objective gather per step",
                        "mission": args.mission, "aircraft": "+".join(aircraft), "ts": args.ts, "pattern": args.pattern,
-                       "batch_per_gpu": B, "global_batch": total, "x_buffers": len(dXs),
+                       "batch_per_gpu": B, "global_batch": total, "x_buffers": r["x_buffers"],
                        "parallelism": (f"batch-sharded x{world}, {backend} all-gather of objectives") if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": "tolfg::fg_kernel (the whole evaluation: the last tile wave of a trajectory finalizes it)",
-                         "kernel_ms": kern_ms,
+                         "kernel_ms": r["kern_ms"],
                          "timing": "kernel_ms = (HIP event after the last launch - HIP event before the first) / steps, on the launch "
                                    "stream, over the timed region: it contains the gap between dependent launches, so the kernel "
                                    "itself is no slower than this. instrumented_*: a second pass with start/stop events attached "
                                    "to every dispatch, as rocprofv3 --kernel-trace does; dispatch profiling itself lengthens every "
                                    "launch (profiles/r02_event_cost.md)",
-                         "instrumented_kernel_ms": inst_ms, "instrumented_kernel_min_ms": inst_min_ms, "instrumented_ms_per_step": inst_step_ms,
+                         "instrumented_kernel_ms": r["inst_ms"], "instrumented_kernel_min_ms": r["inst_min_ms"], "instrumented_ms_per_step": r["inst_step_ms"],
                          "algorithmic_bytes_per_launch": alg_bytes,
-                         "bytes_per_node": alg_bytes / (B * args.ts)},
+                         "bytes_per_node": alg_bytes / max(B * args.ts, 1)},
         }
+        if world > 1:
+            line["gather_us"] = r["gather_us"]
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
-        if world == 1 and not args.no_configs:
-            del dXs, dF, dG
-            torch.cuda.empty_cache()
-            line["configs"] = config_records(tol_amd, torch, local)
-            line["callback"] = [r for r in line["configs"] if r["mode"] == "callback"]
-            if args.pattern == "reference" and args.mission != "mixed":
-                line["next_compact_pattern"] = compact_side_run(tol_amd, torch, args, B, local)
-                line["two_batches_two_streams"] = two_streams_record(tol_amd, torch, args, B, local)
-                # the same shape at four times the batch (3.5 GB of F + G): what a launch reaches once its fill and
-                # drain are a smaller share; a side record, the headline batch stays as it was
-                big = device_record(tol_amd, torch, 9, "headline shape at %d trajectories per GPU" % (4 * B), args.mission,
-                                    (args.aircraft,), args.ts, 4 * B, args.dtype, 30, local, 2)
-                del big["config"]
-                line["headline_shape_larger_batch"] = big
+        if configs is not None:
+            line["configs"] = configs
+            if world == 1:
+                line["configs"] = single_gpu_records(tol_amd, torch, local) + configs
+                line["configs"].sort(key=lambda c: (c["config"], c["mode"] != "device-resident", -c.get("batch", 0)))
+                line["callback"] = [c for c in line["configs"] if c["mode"] == "callback"]
+                # side records on the round-2 headline shape (S10 / tempest / 4096): not BASELINE configs
+                side = argparse.Namespace(mission="S10", aircraft="tempest", ts=200, dtype="f64", x_buffers=args.x_buffers)
+                s4096 = device_record(tol_amd, torch, 9, "side: problemS10/tempest/ts=200, 4096 trajectories (the round-1/2 headline shape)",
+                                      "S10", ("tempest",), 200, 4096, "f64", 100, local)
+                del s4096["config"]
+                line["s10_batch_4096"] = s4096
+                line["next_compact_pattern"] = compact_side_run(tol_amd, torch, side, 4096, local)
+                line["two_batches_two_streams"] = two_streams_record(tol_amd, torch, side, 4096, local)
         print(json.dumps(line), flush=True)
 
     if world > 1:
-        fence()
+        job.barrier()
         dist.destroy_process_group()
 
 

@@ -257,15 +257,17 @@ def compact_index(problem):
 
 
 def eval_batch(problems, X, nthreads=1, opt="O2"):
-    """Evaluate a list of oracle Problems (same mission and N) on the rows of X."""
+    """Evaluate a list of oracle Problems (same N; missions may differ: rows are then sized for the larger
+    mission and each row holds its own mission's neF / neG entries) on the rows of X."""
     B = len(problems)
     p0 = problems[0]
     X = np.ascontiguousarray(X, dtype=np.float64)
-    assert X.shape == (B, p0.n)
+    assert X.shape == (B, p0.n) and all(p.n == p0.n for p in problems)
     arr = (OrcProblem * B)(*[p.c for p in problems])
-    F = np.zeros((B, p0.neF))
-    G = np.zeros((B, p0.neG))
-    used = lib(opt).orc_eval_batch(arr, B, _d(X), p0.n, _d(F), p0.neF, _d(G), p0.neG, int(nthreads))
+    neF, neG = max(p.neF for p in problems), max(p.neG for p in problems)
+    F = np.zeros((B, neF))
+    G = np.zeros((B, neG))
+    used = lib(opt).orc_eval_batch(arr, B, _d(X), p0.n, _d(F), neF, _d(G), neG, int(nthreads))
     return F, G, used
 
 

@@ -26,9 +26,10 @@ def rows(path):
 
 def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-    batch = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+    batch = int(sys.argv[2]) if len(sys.argv) > 2 else 8192
     ts = int(sys.argv[3]) if len(sys.argv) > 3 else 200
     dtype = sys.argv[4] if len(sys.argv) > 4 else "f64"
+    mission = sys.argv[5] if len(sys.argv) > 5 else "mixed"
     src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
     dst = os.path.join(ROOT, "profiles")
     os.makedirs(dst, exist_ok=True)
@@ -50,12 +51,18 @@ def main():
     read_bytes = 2.0 * fetch_kib * 1024.0        # gfx950 correction for wide coalesced reads
     write_bytes = write_kib * 1024.0
     elem = 8 if dtype == "f64" else 4
-    n, neF, neG = 11 * (ts + 1) + 1, 8 * ts + 1 + 11, 107 * ts + 37    # S10
+    n = 11 * (ts + 1) + 1
+    sizes = {"S10": (8 * ts + 1 + 11, 107 * ts + 37), "G7": (8 * ts + 1 + 12, 105 * ts + 48)}
+    if mission == "mixed":      # mission = b mod 2: half the rows of each (batch even)
+        neF = (sizes["S10"][0] + sizes["G7"][0]) / 2
+        neG = (sizes["S10"][1] + sizes["G7"][1]) / 2
+    else:
+        neF, neG = sizes[mission]
     alg = elem * batch * (n + neF + neG)
     avg_ns = float(fg["AverageNs"])
     t0 = trace[0]
     md = []
-    md.append(f"# rocprofv3 summary `{tag}` -- bench.py, S10/tempest/ts={ts}/{dtype}, batch {batch} per GPU, 1 MI355X\n")
+    md.append(f"# rocprofv3 summary `{tag}` -- bench.py, {mission}/ts={ts}/{dtype}, batch {batch} per GPU, 1 MI355X\n")
     md.append("Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 50 --warmup 5 "
               "--no-cpu-baseline --no-configs` (tools/profile_gpu.sh); counters from two further passes of the same "
               "command with `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE`.\n")
@@ -69,8 +76,8 @@ def main():
               f"rocprofv3's trace columns: VGPR_Count {t0['VGPR_Count']}, Accum_VGPR_Count {t0['Accum_VGPR_Count']}, "
               f"SGPR_Count {t0['SGPR_Count']}, LDS_Block_Size {t0['LDS_Block_Size']} B, Scratch_Size {t0['Scratch_Size']} B "
               f"-- these are the profiler's own accounting (its VGPR figure is not the code object's, and it shows the "
-              f"STATIC LDS only).  The code object (tools/isa_report.py) says next_free_vgpr 100, no scratch; the kernel's LDS "
-              f"is dynamic: 17 920 B are used per workgroup and the launch requests 160 KiB / cap so that at most `cap` "
+              f"STATIC LDS only).  The code object (tools/isa_report.py) has no scratch; the kernel's LDS "
+              f"is dynamic: (nt + 1) x 35 elements are used per workgroup and the launch requests 160 KiB / cap so that at most `cap` "
               f"one-wave workgroups share a CU (tol_amd/csrc/plan.cpp)")
     md.append(f"- algorithmic bytes per launch = {elem} B x {batch} x (n {n} + neF {neF} + neG {neG}) = {alg/1e6:.2f} MB "
               f"({alg/(batch*ts):.1f} B per node)")
@@ -86,7 +93,7 @@ def main():
     with open(os.path.join(dst, tag + "_summary.md"), "w") as fh:
         fh.write("\n".join(md) + "\n")
     with open(os.path.join(dst, "traffic_latest.json"), "w") as fh:
-        json.dump({"tag": tag, "batch": batch, "ts": ts, "dtype": dtype, "mission": "S10", "pattern": "reference",
+        json.dump({"tag": tag, "batch": batch, "ts": ts, "dtype": dtype, "mission": mission, "pattern": "reference",
                    "source": f"tools/profile_gpu.sh {tag} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
                    "hbm_bytes_per_launch": read_bytes + write_bytes,
                    "read_bytes": read_bytes, "write_bytes": write_bytes,

@@ -14,8 +14,9 @@ for c in d.get("configs", []):
         print("  config %d callback: %.1f us/call native (%.1f via ctypes; F only %.1f) = %.3g node-evals/s  [%s]"
               % (c["config"], c["us_per_call"], c["us_per_call_via_python_ctypes"], c.get("us_per_call_needF_only", float("nan")), c["node_evals_per_s"], c["workload"]))
     else:
-        print("  config %d B=%d %s: step %.1f us, per launch %.1f us (instrumented %.1f, min %.1f) = %.0f GB/s = %.3f of peak, %.3g node-evals/s  [%s]"
-              % (c["config"], c["batch"], c["dtype"], 1e3 * c["ms_per_step"], c["eval_us"], c.get("eval_us_instrumented", float("nan")),
+        extra = "" if c.get("n_gpus", 1) == 1 else " (%d per GPU x %d GPUs, gather %.1f us)" % (c["batch_per_gpu"], c["n_gpus"], c["gather_us"])
+        print("  config %d B=%d%s %s: step %.1f us, per launch %.1f us (instrumented %.1f, min %.1f) = %.0f GB/s = %.3f of peak, %.3g node-evals/s  [%s]"
+              % (c["config"], c["batch"], extra, c["dtype"], 1e3 * c["ms_per_step"], c["eval_us"], c.get("eval_us_instrumented", float("nan")),
                  c.get("eval_min_us_instrumented", c.get("eval_min_us", float("nan"))), c["achieved_GBs"], c["frac_of_hbm_peak"],
                  c["node_evals_per_s"], c["workload"]))
 if "cpu_baseline" in d:
@@ -29,6 +30,7 @@ if "two_batches_two_streams" in d:
     c = d["two_batches_two_streams"]
     print("  two batches on two streams: %.1f us per evaluation, %.4g node-evals/s = %.3f of peak (whole wall time)"
           % (c["us_per_evaluation"], c["node_evals_per_s"], c["frac_of_hbm_peak"]))
-if "headline_shape_larger_batch" in d:
-    c = d["headline_shape_larger_batch"]
-    print("  %s: evaluation %.1f us = %.3f of peak, whole step %.4g node-evals/s" % (c["workload"], c["eval_us"], c["frac_of_hbm_peak"], c["node_evals_per_s"]))
+for key in ("s10_batch_4096", "headline_shape_larger_batch"):
+    if key in d:
+        c = d[key]
+        print("  %s: evaluation %.1f us = %.3f of peak, whole step %.4g node-evals/s" % (c["workload"], c["eval_us"], c["frac_of_hbm_peak"], c["node_evals_per_s"]))
