@@ -91,6 +91,10 @@ typedef struct tolfg_config {
                                  the reference does (src/DefineFG.cpp:16-46, src/problem.cpp:740-756);
                                  default 0                                                          */
     int    pattern;           /* TOLFG_PATTERN_*; default REFERENCE                                */
+    int    persistent_arrays; /* 1 = the caller promises that the x, F and G arrays it hands to DEFINEGusrfg_ stay
+                                 allocated, at their addresses, until tolfg_forget_arrays() / tolfg_destroy() --
+                                 true for snOptA, whose x, F, G are sections of its workspace for the whole solve
+                                 (ref: src/snoptProblem.cpp:468-477).  See "Arrays used in place".  Default 0.     */
 } tolfg_config;
 
 void tolfg_config_default(tolfg_config *cfg);
@@ -151,8 +155,29 @@ void DEFINEGusrfg_(int *Status, int *n, double x[],
                    int iu[], int *leniu,
                    double ru[], int *lenru);
 
+/* Arrays used in place.
+ * By default every DEFINEGusrfg_ call copies x into, and F and G out of, pinned staging buffers of the library
+ * (17 + 190 KB at ts = 200): safe for any caller, whatever it does with its arrays between calls.
+ * The kernel can instead read x and write F and G where they lie in the caller's memory (no copies: 18.5 vs ~30 us
+ * per call at ts = 200).  That needs the arrays pinned and mapped into the GPU's address space
+ * (hipHostRegister), and a pinning is tied to the ADDRESS, not to the allocation: an array that is freed and
+ * re-allocated -- even at the same address -- is no longer the memory the GPU writes.  So in-place use is a contract
+ * the caller enters explicitly, one of two ways:
+ *   * tolfg_register_arrays(p, x, F, G): these arrays (16-byte aligned; any may be NULL) are used in place from
+ *     now on, whenever a call passes exactly these pointers; or
+ *   * tolfg_config.persistent_arrays = 1: an array passed to two DEFINEGusrfg_ calls in a row is taken to be one
+ *     the caller keeps and is registered on that second call (the drop-in choice for snOptA, which hands sections
+ *     of its own workspace that the driver never sees).
+ * Either way the caller must call tolfg_forget_arrays(p) BEFORE freeing or re-allocating any such array (it waits
+ * for the evaluation in flight, unpins everything and returns to the staging copies); tolfg_destroy does the same.
+ * tolfg_registered_arrays(p) tells how many arrays are pinned at the moment. */
+int tolfg_register_arrays(tolfg_problem *p, double *x, double *F, double *G);
+int tolfg_forget_arrays(tolfg_problem *p);
+int tolfg_registered_arrays(const tolfg_problem *p);
+
 /* Measurement aid: enter DEFINEGusrfg_ `calls` times from native code through an snFunA function pointer,
- * the way snOptA does (x, F, G: caller arrays of the problem's sizes, the same ones every call), after
+ * the way snOptA does (x, F, G: caller arrays of the problem's sizes, the same ones every call, used in place for
+ * the duration of this function where they are 16-byte aligned, and forgotten again before it returns), after
  * `warm` untimed calls; *us_per_call receives the mean wall time of one call.  needF / needG are passed through
  * (snOptA asks for F alone during its line searches).  Returns the last *Status the callback left (1 = untouched)
  * or a negative TOLFG_ERR_*. */
@@ -238,6 +263,13 @@ int  tolfg_batch_bounds(const tolfg_batch *b, int t, double zi,
 int  tolfg_batch_eval(tolfg_batch *b, int B,
                       const void *dX, long ldx, void *dF, long ldf, void *dG, long ldg,
                       const void *dWind, int needF, int needG, void *dObj, void *stream);
+/* Health of the evaluations issued so far, to be asked after they have completed (stream synchronisation): TOLFG_OK,
+ * or TOLFG_ERR_HIP when a launch lost an objective partial -- the one-launch evaluation hands the tiles' objective
+ * terms to the finalizing wave through polled slots whose "empty" marker is a NaN bit pattern (0xFFFBADADFFFBADAD); an x
+ * that carries exactly that NaN makes a slot look empty for good, the wave gives up after a bounded wait, F[0] of that
+ * trajectory is a NaN and this call says so (and clears the condition).  tolfg_batch_eval itself refuses to start
+ * (TOLFG_ERR_HIP) while the condition is pending; DEFINEGusrfg_ reports it as *Status = -2. */
+int  tolfg_batch_status(tolfg_batch *b);
 /* dObj[t] = F[t][0] for t in [0,B): the per-trajectory objectives, contiguous, ready for the
  * RCCL all-gather across GPUs (a separate small kernel; tolfg_batch_eval's dObj does it for free). */
 int  tolfg_batch_objectives(tolfg_batch *b, int B, const void *dF, long ldf, void *dObj, void *stream);

@@ -26,6 +26,7 @@ int main(int argc, char **argv)
     cfg.ts = std::atoi(argv[3]);
     cfg.east_goal = 400; cfg.north_goal = 0; cfg.up_goal = 70; cfg.up = 100;
     cfg.radius_goal = cfg.mission[0] == 'S' ? 100 : 0;
+    cfg.persistent_arrays = 1;                // like snOptA: the same x, F, G every call, until tolfg_forget_arrays
     tolfg_problem *p = nullptr;
     if (tolfg_create(&cfg, &p) != TOLFG_OK) { std::fprintf(stderr, "create: %s\n", tolfg_last_error()); return 1; }
     tolfg_set_current(p);
@@ -40,8 +41,11 @@ int main(int argc, char **argv)
     snFunA usrfun = DEFINEGusrfg_;            // must be assignable without a cast
     for (int i = 0; i < neG; i++) { iGfun[i]++; jGvar[i]++; }       // src/snoptProblem.cpp:460-465
     int Status = 1, needF = 1, needG = 1, lencu = 0, leniu = 0, lenru = 0;
-    usrfun(&Status, &n, x.data(), &needF, &neF, F.data(), &needG, &neG, G.data(), nullptr, &lencu, nullptr, &leniu,
-           nullptr, &lenru);
+    for (int call = 0; call < 3; call++)      // the second call in a row pins the arrays, the third runs in place
+        usrfun(&Status, &n, x.data(), &needF, &neF, F.data(), &needG, &neG, G.data(), nullptr, &lencu, nullptr, &leniu,
+               nullptr, &lenru);
+    if (Status == 1 && tolfg_registered_arrays(p) < 2) { std::fprintf(stderr, "arrays were not used in place\n"); return 4; }
+    if (tolfg_forget_arrays(p) != TOLFG_OK || tolfg_registered_arrays(p) != 0) return 5;
     for (int i = 0; i < neG; i++) { iGfun[i]--; jGvar[i]--; }
     std::printf("status %d n %d neF %d neG %d\n", Status, n, neF, neG);
     for (int i = 0; i < neF; i++) std::printf("F %.17g\n", F[i]);

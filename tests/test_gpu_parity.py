@@ -302,11 +302,12 @@ def test_batched_need_flags_and_repeated_launches(tolfg, oracle, mission):
 
 @pytest.mark.parametrize("mission,N", [("S10", 200), ("G7", 64), ("S10", 33)])
 def test_callback_with_the_callers_own_arrays_kept_across_calls(tolfg, oracle, mission, N):
-    """snOptA hands DEFINEGusrfg_ the SAME x, F and G arrays call after call.  The library registers an array it sees
-    twice and lets the kernel read x from it and write F and G into it (no staging copies); x changes in place between
-    calls.  Every call must return the right numbers (ts = 33: n is odd, x then still goes through the pinned copy)."""
+    """snOptA hands DEFINEGusrfg_ the SAME x, F and G arrays call after call.  With tolfg_config.persistent_arrays (the
+    driver's promise that they stay put) the library registers an array it sees twice in a row and lets the kernel read
+    x from it and write F and G into it (no staging copies); x changes in place between calls.  Every call must return
+    the right numbers (ts = 33: n is odd, x then still goes through the pinned copy)."""
     import ctypes as C
-    p = tolfg.Problem(mission, "skywalker", ts=N, radius_goal=100.0 if mission == "S10" else 0.0)
+    p = tolfg.Problem(mission, "skywalker", ts=N, radius_goal=100.0 if mission == "S10" else 0.0, persistent_arrays=True)
     o = oracle.Problem(mission, "skywalker", N=N, radius_goal=100.0 if mission == "S10" else 0.0)
     lib = tolfg.lib()
     x = np.ascontiguousarray(o.x0(), dtype=np.float64)
@@ -326,4 +327,5 @@ def test_callback_with_the_callers_own_arrays_kept_across_calls(tolfg, oracle, m
         Fo, Go = o.eval(x)
         assert_close(F, Fo, what=f"call {call} F")
         assert_close(G, np.where(o.undefined_mask(), 0.0, Go), mask=o.undefined_mask(), what=f"call {call} G")
+        assert p.registered_arrays() == (0 if call == 0 else (3 if p.n % 2 == 0 else 2))
     p.close()

@@ -31,7 +31,7 @@ class Config(C.Structure):
                 ("ts", C.c_int), ("windmodel", C.c_int),
                 ("Vref", C.c_double), ("href", C.c_double),
                 ("xi", C.c_double), ("yi", C.c_double), ("zi", C.c_double),
-                ("device", C.c_int), ("debug_dumps", C.c_int), ("pattern", C.c_int)]
+                ("device", C.c_int), ("debug_dumps", C.c_int), ("pattern", C.c_int), ("persistent_arrays", C.c_int)]
 
 
 class Traj(C.Structure):
@@ -81,6 +81,9 @@ SYMBOLS = {
     "tolfg_get_current": (C.c_void_p, []),
     "tolfg_handle_index": (C.c_int, [C.c_void_p]),
     "DEFINEGusrfg_": (None, [_ip, _ip, _dp, _ip, _ip, _dp, _ip, _ip, _dp, C.c_char_p, _ip, _ip, _ip, _dp, _ip]),
+    "tolfg_register_arrays": (C.c_int, [C.c_void_p, _dp, _dp, _dp]),
+    "tolfg_forget_arrays": (C.c_int, [C.c_void_p]),
+    "tolfg_registered_arrays": (C.c_int, [C.c_void_p]),
     "tolfg_time_callback": (C.c_int, [C.c_void_p, _dp, _dp, _dp, C.c_int, C.c_int, C.c_int, C.c_int, _dp]),
     "tolfg_modelWind": (C.c_int, [C.c_void_p, _dp]),
     "tolfg_computeF": (C.c_int, [C.c_void_p, _dp, _dp]),
@@ -99,6 +102,7 @@ SYMBOLS = {
     "tolfg_batch_bounds": (C.c_int, [C.c_void_p, C.c_int, C.c_double, _dp, _dp, _dp, _dp]),
     "tolfg_batch_eval": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_long, C.c_void_p, C.c_long,
                                    C.c_void_p, C.c_long, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "tolfg_batch_status": (C.c_int, [C.c_void_p]),
     "tolfg_batch_objectives": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_long, C.c_void_p, C.c_void_p]),
     "tolfg_batch_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "tolfg_batch_kernel_time": (C.c_int, [C.c_void_p, _dp, _dp]),

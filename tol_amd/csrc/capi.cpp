@@ -222,6 +222,24 @@ void DEFINEGusrfg_(int *Status, int *n, double x[], int *needF, int *neF, double
     }
 }
 
+int tolfg_register_arrays(tolfg_problem *h, double *x, double *F, double *G)
+{
+    if (!h) return fail(TOLFG_ERR_ARG, "null problem");
+    return guarded([&] { h->p->register_arrays(x, F, G); });
+}
+
+int tolfg_forget_arrays(tolfg_problem *h)
+{
+    if (!h) return fail(TOLFG_ERR_ARG, "null problem");
+    return guarded([&] { h->p->forget_arrays(); });
+}
+
+int tolfg_registered_arrays(const tolfg_problem *h)
+{
+    if (!h) return fail(TOLFG_ERR_ARG, "null problem");
+    return h->p->registered_arrays();
+}
+
 int tolfg_time_callback(tolfg_problem *h, const double *x, double *F, double *G, int needF, int needG, int warm, int calls,
                         double *us_per_call)
 {
@@ -233,12 +251,18 @@ int tolfg_time_callback(tolfg_problem *h, const double *x, double *F, double *G,
     tolfg_set_current(h);
     int Status = 1, n = h->p->n, neF = h->p->neF, neG = h->p->neG, zero = 0;
     int wantF = needF ? 1 : 0, wantG = needG ? 1 : 0;
-    std::vector<double> xs(x, x + n);
-    for (int i = 0; i < warm; ++i) usrfun(&Status, &n, xs.data(), &wantF, &neF, F, &wantG, &neG, G, nullptr, &zero, nullptr, &zero, nullptr, &zero);
+    // the caller's arrays, the same ones every call, as snOptA's are: used in place while this function runs (where
+    // aligned) and forgotten before it returns, so nothing stays pinned that the caller may free
+    double *xs = const_cast<double *>(x);          // snFunA takes double x[]; the callback only reads it
+    auto al = [](const void *p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; };
+    const int rc = guarded([&] { h->p->register_arrays(al(xs) ? xs : nullptr, al(F) ? F : nullptr, al(G) ? G : nullptr); });
+    if (rc != TOLFG_OK) { tolfg_set_current(keep); return rc; }
+    for (int i = 0; i < warm; ++i) usrfun(&Status, &n, xs, &wantF, &neF, F, &wantG, &neG, G, nullptr, &zero, nullptr, &zero, nullptr, &zero);
     const auto t0 = std::chrono::steady_clock::now();
-    for (int i = 0; i < calls; ++i) usrfun(&Status, &n, xs.data(), &wantF, &neF, F, &wantG, &neG, G, nullptr, &zero, nullptr, &zero, nullptr, &zero);
+    for (int i = 0; i < calls; ++i) usrfun(&Status, &n, xs, &wantF, &neF, F, &wantG, &neG, G, nullptr, &zero, nullptr, &zero, nullptr, &zero);
     const auto t1 = std::chrono::steady_clock::now();
     *us_per_call = std::chrono::duration<double, std::micro>(t1 - t0).count() / calls;
+    (void)guarded([&] { h->p->forget_arrays(); });
     tolfg_set_current(keep);
     return Status;
 }
@@ -388,6 +412,15 @@ int tolfg_batch_objectives(tolfg_batch *h, int B, const void *dF, long ldf, void
 {
     if (!h) return fail(TOLFG_ERR_ARG, "null batch");
     return guarded([&] { h->b->objectives(B, dF, ldf, dObj, static_cast<hipStream_t>(stream)); });
+}
+
+int tolfg_batch_status(tolfg_batch *h)
+{
+    if (!h) return fail(TOLFG_ERR_ARG, "null batch");
+    if (h->b->take_lost_partial())
+        return fail(TOLFG_ERR_HIP, "an evaluation of this batch lost an objective partial: its F[0] is not a number (does x carry "
+                                   "NaNs?); the outputs of that evaluation must not be used");
+    return TOLFG_OK;
 }
 
 int tolfg_batch_set_timing(tolfg_batch *h, int enable)

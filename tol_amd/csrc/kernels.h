@@ -79,6 +79,8 @@ struct FgArgs {
                            // every slot is "empty" (kEmptySlotWord) between launches
     unsigned *counter;     // [B + 1]: [0, B) arrival counters of the fused path, [B] departures of the callback's
                            // completion word; all zero before a launch, put back to zero by the launch itself
+    unsigned *status;      // host-mapped word (or nullptr): set to 1 by a finalizing wave that gave up waiting for an objective
+                           // partial (fused path; only an input that carries the empty-slot marker itself can cause that)
     // Completion word for the SNOPT callback (host-mapped, or nullptr): when every wave's stores are visible
     // to the host, the last wave to leave writes done_seq there, so the caller can spin on it instead of
     // synchronising the stream.

@@ -919,10 +919,12 @@ __device__ __forceinline__ void signal_done(const FgArgs &a, int participants, b
         unsigned *dep = a.counter + a.B;
         bool last = true;
         if (participants > 1) {
-            last = __hip_atomic_fetch_add(dep, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(participants - 1);
+            // acquire-release: the last arrival's completion word is ordered after every other participant's stores by
+            // the memory model, not just by what the hardware happens to do
+            last = __hip_atomic_fetch_add(dep, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(participants - 1);
             if (last) __hip_atomic_store(dep, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        if (last) __hip_atomic_store(a.done, a.done_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (last) __hip_atomic_store(a.done, a.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -932,21 +934,25 @@ __device__ __forceinline__ void signal_done(const FgArgs &a, int participants, b
 // launch on other XCDs wrote them -- sc1 loads that poll until the slot is no longer empty, then
 // empty it again for the next launch.
 template <typename T, bool POLL>
-__device__ __forceinline__ void sum_partials(const double *part, int tiles, int lane, T &sumT, T &sumP)
+__device__ __forceinline__ void sum_partials(const double *part, int tiles, int lane, T &sumT, T &sumP, unsigned *status = nullptr)
 {
     T st = T(0), sp = T(0);
+    bool lost = false;
     for (int t = lane; t < tiles; t += TILE) {
         if constexpr (POLL) {
             unsigned long long *q = reinterpret_cast<unsigned long long *>(const_cast<double *>(part)) + 2 * t;
             unsigned long long b0, b1;
             // every tile wave stores its payload before it arrives, so the slots fill within a store
-            // round trip; the spin bound only guards against an input that carries the marker itself
-            for (int spin = 0; spin < (1 << 20); spin++) {
+            // round trip; the spin bound only guards against an input whose objective terms ARE the marker
+            // (a NaN with that payload in x): the launch then ends, F[0] is that NaN, and the batch's status
+            // word tells the host that a partial was lost (tolfg_batch_status, *Status = -2 in the callback)
+            for (int spin = 0; spin < (1 << 16); spin++) {
                 b0 = __hip_atomic_load(q + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 b1 = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (b0 != kEmptySlot && b1 != kEmptySlot) break;
                 __builtin_amdgcn_s_sleep(8);
             }
+            lost |= b0 == kEmptySlot || b1 == kEmptySlot;
             __hip_atomic_store(q + 0, kEmptySlot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(q + 1, kEmptySlot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             st += T(__builtin_bit_cast(double, b0));
@@ -955,6 +961,9 @@ __device__ __forceinline__ void sum_partials(const double *part, int tiles, int 
             st += T(part[2 * t + 0]);
             sp += T(part[2 * t + 1]);
         }
+    }
+    if constexpr (POLL) {
+        if (lost && status) __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     sumT = wave_sum(st);
     sumP = wave_sum(sp);
@@ -978,7 +987,7 @@ __device__ __forceinline__ void run_tile(const FgArgs &a, T *lds, int item, int 
         if (old == (unsigned)(at.tiles - 1)) {         // wave-uniform: every tile of b has arrived
             if (lane == 0) __hip_atomic_store(pub.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             T st = T(0), sp = T(0);
-            if (a.needF) sum_partials<T, true>(a.partial + 2 * (long)at.first, at.tiles, lane, st, sp);
+            if (a.needF) sum_partials<T, true>(a.partial + 2 * (long)at.first, at.tiles, lane, st, sp, a.status);
             finalize_body<T, MISSION, PAT>(a, b, lane, st, sp);
         }
     } else if (a.needF && lane == 0) {

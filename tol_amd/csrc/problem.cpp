@@ -159,6 +159,7 @@ batch::~batch()
     if (d_traj_) (void)hipFree(d_traj_);
     if (d_partial_) (void)hipFree(d_partial_);
     if (d_counter_) (void)hipFree(d_counter_);
+    if (h_status_) (void)hipHostFree(h_status_);
     if (d_grid_) (void)hipFree(d_grid_);
     for (hipEvent_t e : ev_) if (e) (void)hipEventDestroy(e);
 }
@@ -247,7 +248,19 @@ void batch::upload()
     }
     check(hipMemcpy(d_traj_, dev_traj_.data(), sizeof(TrajDev) * (size_t)ntraj_, hipMemcpyHostToDevice),
           "hipMemcpy(traj)");
+    if (!h_status_) {
+        check(hipHostMalloc(reinterpret_cast<void **>(&h_status_), 64, hipHostMallocMapped), "hipHostMalloc(status)");
+        *h_status_ = 0;
+        check(hipHostGetDevicePointer(reinterpret_cast<void **>(&d_status_), h_status_, 0), "hipHostGetDevicePointer(status)");
+    }
     uploaded_ = true;
+}
+
+bool batch::take_lost_partial()
+{
+    if (!h_status_ || __atomic_load_n(h_status_, __ATOMIC_ACQUIRE) == 0) return false;
+    __atomic_store_n(h_status_, 0u, __ATOMIC_RELEASE);
+    return true;
 }
 
 void batch::eval(int B, const void *dX, long ldx, void *dF, long ldf, void *dG, long ldg, const void *dWind,
@@ -261,6 +274,9 @@ void batch::eval(int B, const void *dX, long ldx, void *dF, long ldf, void *dG, 
     if (windmodel_ == TOLFG_WIND_TABLE && !dWind) throw std::invalid_argument("eval: table wind needs dWind");
     if (windmodel_ == TOLFG_WIND_GRID && !d_grid_) throw std::invalid_argument("eval: grid wind needs tolfg_*_set_wind_grid");
     if (!uploaded_) upload();
+    if (take_lost_partial())
+        throw hip_failure("an earlier evaluation of this batch lost an objective partial: its F[0] is not a number (does x carry "
+                          "NaNs?); the outputs of that evaluation must not be used");
     FgArgs a = args_;
     // a handful of short trajectories (the SNOPT callback is B = 1): one launch, whole trajectory per
     // workgroup (measured per call: ts=100 24.7 vs 29.2 us, ts=200 29.7 vs 33.1 us; at ts=500, 8 waves
@@ -307,6 +323,7 @@ void batch::eval(int B, const void *dX, long ldx, void *dF, long ldf, void *dG, 
     }
     a.partial = d_partial_;
     a.counter = d_counter_;
+    a.status = d_status_;
     a.fused = ((fused_forced_ >= 0 ? fused_forced_ : lp.fused) || done) ? 1 : 0;   // a completion word needs the single-launch form
     // the two-launch form leaves its partial sums in the slots; the single-launch form polls for slots that are still
     // "empty", so a batch that changes form between evaluations (compact pattern across the cache threshold) refills them
@@ -418,6 +435,7 @@ problem::problem(const tolfg_config &cfg, int mission_id)
     if (sz.mission != mission_id) throw std::invalid_argument("mission mismatch");
     n = sz.n; neF = sz.neF; neG = sz.neG;
     east = cfg.east; north = cfg.north; up = cfg.up;
+    persistent_arrays_ = cfg.persistent_arrays != 0;
     // goals ENU -> NED (ref: src/problem.cpp:24-27)
     yg = cfg.east_goal; xg = cfg.north_goal; zg = -cfg.up_goal; rg = cfg.radius_goal;
     mission = cfg.mission; aircraft_type = cfg.aircraft;
@@ -474,8 +492,7 @@ problem::~problem()
     if (hF_) (void)hipHostFree(hF_);
     if (hG_) (void)hipHostFree(hG_);
     if (done_) (void)hipHostFree(done_);
-    for (const HostView &v : views_) if (v.dev) (void)hipHostUnregister(v.base);
-    clear_errors();
+    forget_arrays();
     if (dX_) (void)hipFree(dX_);
     if (dF_) (void)hipFree(dF_);
     if (dG_) (void)hipFree(dG_);
@@ -509,8 +526,9 @@ void *problem::device_view(void *p, size_t bytes)
     for (HostView &v : views_)
         if (v.base == p && v.bytes >= bytes) {
             if (v.dev || v.seen != 1) return v.dev;
-            // Second sight of this array in a row: it is one the caller keeps (SNOPT's own F and G).  Pin it
-            // and map it into the device's address space; a failure is remembered (seen = 2, dev = nullptr).
+            // Second sight of this array in a row under tolfg_config.persistent_arrays: it is one the caller keeps
+            // (SNOPT's own x, F and G).  Pin it and map it into the device's address space; a failure is
+            // remembered (seen = 2, dev = nullptr).
             v.seen = 2;
             void *dev = nullptr;
             if (hipHostRegister(p, v.bytes, hipHostRegisterMapped) == hipSuccess && hipHostGetDevicePointer(&dev, p, 0) == hipSuccess)
@@ -518,15 +536,59 @@ void *problem::device_view(void *p, size_t bytes)
             clear_errors();
             return v.dev;
         }
+    // Without the caller's word that its arrays persist nothing is ever pinned by address: an array that was freed and
+    // re-allocated at the same address is indistinguishable from one that was kept, and a stale pinning would have
+    // the GPU write into pages the new array no longer owns.
+    if (!persistent_arrays_) return nullptr;
     // First sight: remember it, use the staging copy this time (arrays that change from call to call are
     // never registered -- registering costs more than the copy it saves)
-    if (views_.size() >= 16) {
-        for (const HostView &v : views_) if (v.dev) (void)hipHostUnregister(v.base);
-        clear_errors();
-        views_.clear();
-    }
+    if (views_.size() >= 16) forget_arrays();
     views_.push_back(HostView{p, bytes, nullptr, 1});
     return nullptr;
+}
+
+void problem::register_arrays(double *xu, double *Fu, double *Gu)
+{
+    ensure_device();
+    check(hipSetDevice(eng_->device()), "hipSetDevice");
+    const struct { double *p; size_t bytes; const char *what; } req[3] = {
+        {xu, sizeof(double) * (size_t)n, "x"}, {Fu, sizeof(double) * (size_t)neF, "F"}, {Gu, sizeof(double) * (size_t)neG, "G"}};
+    for (const auto &r : req) {
+        if (!r.p) continue;
+        if (reinterpret_cast<uintptr_t>(r.p) % 16 != 0)
+            throw std::invalid_argument(std::string("register_arrays: ") + r.what + " must start on a 16-byte boundary");
+        bool known = false;
+        for (HostView &v : views_)
+            if (v.base == r.p) {
+                known = v.dev != nullptr && v.bytes >= r.bytes;
+                if (!known && v.dev) { (void)hipHostUnregister(v.base); v.dev = nullptr; }
+                if (!known) { v.bytes = r.bytes; v.seen = 1; }
+            }
+        if (known) continue;
+        void *dev = nullptr;
+        check(hipHostRegister(r.p, r.bytes, hipHostRegisterMapped), "hipHostRegister");
+        const hipError_t e = hipHostGetDevicePointer(&dev, r.p, 0);
+        if (e != hipSuccess) { (void)hipHostUnregister(r.p); check(e, "hipHostGetDevicePointer"); }
+        bool placed = false;
+        for (HostView &v : views_) if (v.base == r.p) { v.dev = dev; v.seen = 2; placed = true; }
+        if (!placed) views_.push_back(HostView{r.p, r.bytes, dev, 2});
+    }
+}
+
+void problem::forget_arrays()
+{
+    if (stream_) (void)hipStreamSynchronize(stream_);     // nothing in flight may still address them
+    for (const HostView &v : views_) if (v.dev) (void)hipHostUnregister(v.base);
+    clear_errors();
+    views_.clear();
+    staged_ = false;
+}
+
+int problem::registered_arrays() const
+{
+    int k = 0;
+    for (const HostView &v : views_) k += v.dev != nullptr;
+    return k;
 }
 
 void problem::stage_and_launch(const double xin[], bool needF, bool needG, double *Fuser, double *Guser, bool caller_keeps_x)
@@ -612,11 +674,15 @@ void problem::collect(bool wantF, double F[], bool wantG, double G[])
             if (c == 0 && wantF && F != landF_) std::memcpy(F, landF_, sizeof(double) * neF);     // F's copy precedes G's on the stream
             std::memcpy(G + lo, hG_ + lo, sizeof(double) * (hi - lo));
         }
+        if (eng_->take_lost_partial())
+            throw hip_failure("the evaluation lost an objective partial: F[0] is not a number (does x carry NaNs?)");
         return;
     }
     wait_done();
     if (wantF && F != landF_) std::memcpy(F, landF_, sizeof(double) * neF);
     if (wantG && G != landG_) std::memcpy(G, landG_, sizeof(double) * neG);
+    if (eng_->take_lost_partial())      // DEFINEGusrfg_ turns this into *Status = -2
+        throw hip_failure("the evaluation lost an objective partial: F[0] is not a number (does x carry NaNs?)");
 }
 
 void problem::dump(const char *name, const double *v, int len)

@@ -54,6 +54,9 @@ public:
     const snopt &snopt_params(int mission = -1) const { return sn_.at(slot(mission)); }
 
     void set_wind_grid(const tolfg_wind_grid &g);      // uploads; switches to TOLFG_WIND_GRID
+    // true (once) when an evaluation since the last call lost an objective partial (FgArgs::status); meaningful after
+    // the evaluations have completed.  eval() checks it on entry and refuses to go on (hip_failure).
+    bool take_lost_partial();
     void set_trajectories(int B, const tolfg_traj *trajs);
     int trajectories() const { return ntraj_; }
     const tolfg_traj &trajectory(int t) const { return host_traj_.at(t); }
@@ -96,6 +99,7 @@ private:
     double *d_partial_ = nullptr;
     long partial_cap_ = 0;
     unsigned *d_counter_ = nullptr;
+    unsigned *h_status_ = nullptr, *d_status_ = nullptr;   // pinned, device-mapped: set by a launch that lost an objective partial
     int counter_cap_ = 0;
     int tile_nodes_forced_ = 0;         // TOLFG_TILE_NODES (measurements)
     int fused_forced_ = -1;             // TOLFG_FUSED=0/1 overrides one launch vs fg_kernel + finalize_kernel (measurements)
@@ -134,6 +138,13 @@ public:
     // what DEFINEGusrfg_ uses: one launch, only the requested outputs come back
     void evaluate(const double x[], bool needF, double F[], bool needG, double G[]);
 
+    // Arrays used in place (include/tolfg.h): pin and map the caller's x / F / G (any may be null) for the kernel to
+    // address directly until forget_arrays(); forget_arrays() waits for the stream, unregisters every array and
+    // returns to the staging copies.  registered_arrays(): how many arrays are pinned right now.
+    void register_arrays(double *x, double *F, double *G);
+    void forget_arrays();
+    int registered_arrays() const;
+
     void set_wind_table(const double *wind_enu);   // [12][ts+1], ENU, reference member order
     void set_wind_grid(const tolfg_wind_grid &g);  // wind model 3
     // ref: problem::writeJSON(filename), src/problem.cpp:1247 -- same keys, for the same consumers
@@ -166,11 +177,14 @@ private:
                           bool caller_keeps_x = false);
     void collect(bool wantF, double F[], bool wantG, double G[]);
     void wait_done();
-    // device address of a caller-owned host array, registered on first sight (SNOPT hands the same F and
-    // G arrays to every call: src/snoptProblem.cpp:468-477), or nullptr when it cannot be used directly
+    // Device address of a caller-owned host array the kernel may read / write in place, or nullptr (then the pinned
+    // staging copies are used).  In-place use is a CONTRACT, never a guess (include/tolfg.h, "Arrays used in place"):
+    // arrays named by register_arrays(), or -- only with tolfg_config.persistent_arrays -- an array handed to two
+    // calls in a row (SNOPT hands the same sections of its workspace to every call: src/snoptProblem.cpp:468-477).
     void *device_view(void *p, size_t bytes);
     struct HostView { void *base; size_t bytes; void *dev; int seen; };   // seen: 1 = once, 2 = registration tried
     std::vector<HostView> views_;
+    bool persistent_arrays_ = false;                // tolfg_config.persistent_arrays
     bool register_user_ = true;                     // TOLFG_NO_REGISTER=1 keeps the pinned staging copies
     bool use_flag_ = true;                          // TOLFG_NO_FLAG=1 synchronises the stream instead
     unsigned long long *done_ = nullptr;            // pinned, device-mapped completion word

@@ -47,7 +47,7 @@ class Problem:
     def __init__(self, mission, aircraft="tempest", east=0.0, north=0.0, up=100.0, east_goal=400.0,
                  north_goal=0.0, up_goal=70.0, radius_goal=100.0, ts=0, windmodel=capi.WIND_SHEAR,
                  Vref=2.4, href=10.0, start=(0.0, 0.0, 0.0), device=0, root_path=None, debug_dumps=False,
-                 pattern="reference"):
+                 pattern="reference", persistent_arrays=False):
         L = lib()
         cfg = Config()
         L.tolfg_config_default(C.byref(cfg))
@@ -59,6 +59,7 @@ class Problem:
         cfg.xi, cfg.yi, cfg.zi = start
         cfg.device, cfg.debug_dumps = int(device), int(bool(debug_dumps))
         cfg.pattern = capi.PATTERNS[pattern]
+        cfg.persistent_arrays = int(bool(persistent_arrays))
         self._h = C.c_void_p()
         check(L.tolfg_create(C.byref(cfg), C.byref(self._h)))
         n, neF, neG = C.c_int(), C.c_int(), C.c_int()
@@ -127,10 +128,28 @@ class Problem:
     def handle_index(self):
         return lib().tolfg_handle_index(self._h)
 
-    def define_fg(self, x, needF=True, needG=True, status=1, use_iu=False):
-        """Call DEFINEGusrfg_ with snOptA's argument convention; returns (F, G, Status)."""
-        x = np.ascontiguousarray(x, dtype=np.float64)
-        F, G = np.zeros(self.neF), np.zeros(self.neG)
+    # ---- arrays used in place (include/tolfg.h): the caller's promise that x / F / G stay where they are
+    def register_arrays(self, x=None, F=None, G=None):
+        """Pin and map these numpy arrays (float64, contiguous, 16-byte aligned) for the kernel to use in place whenever
+        define_fg(..., F=F, G=G) passes exactly them; call forget_arrays() before letting go of them."""
+        ptr = lambda a: None if a is None else _d(a)      # noqa: E731
+        check(lib().tolfg_register_arrays(self._h, ptr(x), ptr(F), ptr(G)))
+
+    def forget_arrays(self):
+        check(lib().tolfg_forget_arrays(self._h))
+
+    def registered_arrays(self):
+        k = lib().tolfg_registered_arrays(self._h)
+        if k < 0:
+            check(k)
+        return k
+
+    def define_fg(self, x, needF=True, needG=True, status=1, use_iu=False, F=None, G=None):
+        """Call DEFINEGusrfg_ with snOptA's argument convention; returns (F, G, Status).  F and G are fresh arrays
+        unless given (a caller that keeps its arrays, like SNOPT, passes the same ones every time)."""
+        x = x if isinstance(x, np.ndarray) and x.dtype == np.float64 and x.flags.c_contiguous else np.ascontiguousarray(x, dtype=np.float64)
+        F = np.zeros(self.neF) if F is None else F
+        G = np.zeros(self.neG) if G is None else G
         st, n, neF, neG = C.c_int(status), C.c_int(len(x)), C.c_int(self.neF), C.c_int(self.neG)
         nf, ng = C.c_int(int(needF)), C.c_int(int(needG))
         zero = C.c_int(0)
@@ -214,6 +233,7 @@ class Batch:
         self.mission, self.dtype, self.device = mission, dtype, int(device)
         self.windmodel = windmodel
         self.B = 0
+        self.missions = []
 
     def close(self):
         if getattr(self, "_h", None):
@@ -270,6 +290,8 @@ class Batch:
         return x
 
     def bounds(self, t, zi=0.0):
+        if not 0 <= int(t) < len(self.missions):
+            raise capi.TolfgError(capi.ERR_ARG, f"trajectory {t} is not described (set_trajectories holds {len(self.missions)})")
         neF = self.sizes_of(self.missions[t])[1]
         xl, xu = np.zeros(self.n), np.zeros(self.n)
         Fl, Fu = np.zeros(neF), np.zeros(neF)
@@ -317,6 +339,8 @@ class Batch:
         """Enqueue one evaluation on `stream` (default: torch's current stream).  `obj` (optional,
         B elements) also receives the objectives F[:, 0], contiguous."""
         import torch
+        if not isinstance(X, torch.Tensor):
+            raise capi.TolfgError(capi.ERR_ARG, "X is not a tensor")
         B = X.shape[0] if B is None else B
         self._check(X, "X", B, self.n)
         if needF:
@@ -331,8 +355,10 @@ class Batch:
             self._check(obj, "obj", B, None)
         if stream is None:
             stream = torch.cuda.current_stream(X.device).cuda_stream
-        check(lib().tolfg_batch_eval(self._h, int(B), X.data_ptr(), X.stride(0), F.data_ptr(), F.stride(0),
-                                     G.data_ptr(), G.stride(0), None if wind is None else wind.data_ptr(),
+        Fp, Fs = (F.data_ptr(), F.stride(0)) if needF else (None, 0)
+        Gp, Gs = (G.data_ptr(), G.stride(0)) if needG else (None, 0)
+        check(lib().tolfg_batch_eval(self._h, int(B), X.data_ptr(), X.stride(0), Fp, Fs,
+                                     Gp, Gs, None if wind is None else wind.data_ptr(),
                                      int(needF), int(needG), None if obj is None else obj.data_ptr(),
                                      C.c_void_p(stream)))
 
@@ -369,6 +395,11 @@ class Batch:
         check(lib().tolfg_batch_objectives(self._h, int(B), F.data_ptr(), F.stride(0), out.data_ptr(),
                                            C.c_void_p(stream)))
         return out
+
+    def status(self):
+        """Raises TolfgError(ERR_HIP) when an evaluation since the last call lost an objective partial (ask after the
+        evaluations have completed, e.g. after torch.cuda.synchronize())."""
+        check(lib().tolfg_batch_status(self._h))
 
     def set_timing(self, on=True):
         check(lib().tolfg_batch_set_timing(self._h, int(bool(on))))
