@@ -286,6 +286,43 @@ int  tolfg_batch_kernel_time(tolfg_batch *b, double *avg_ms, double *min_ms);
  * (SURVEY.md section 8d), with each trajectory's own mission sizes and the batch's pattern */
 double tolfg_batch_algorithmic_bytes(const tolfg_batch *b, int B);
 
+/* ------------------------------------------------------------------ 4. several GPUs of one node, one process */
+
+/* A batch sharded over the devices of one node (no reference counterpart; BASELINE north star: "a batch of independent
+ * trajectories shards embarrassingly across the 8 GPUs of one node, RCCL over xGMI only for the final objective
+ * gather").  One process: per device one tolfg_batch, one HIP stream and one issuing host thread, so that the launches
+ * reach the devices side by side.  Trajectory t of `total` lives on device i with lo_i <= t < hi_i, where
+ * [lo_i, hi_i) = tolfg_shard_bounds(total, i, n_devices): contiguous shards, the first total % n_devices one longer.
+ * The only collective is ncclAllGather of the objectives F[t][0] (plus ncclAllReduce for their mean); the RCCL library is
+ * resolved at run time (the copy the process already holds, else the one beside the HIP runtime in use, else
+ * TOLFG_RCCL_LIBRARY), so libtolfg.so has no link-time dependency on it.  cfg->device is ignored (devices[] rules). */
+typedef struct tolfg_multi tolfg_multi;
+int  tolfg_multi_create(const tolfg_batch_config *cfg, const int *devices, int n_devices, tolfg_multi **out);
+void tolfg_multi_destroy(tolfg_multi *m);
+int  tolfg_multi_sizes(const tolfg_multi *m, int *n, int *neF, int *neG);
+/* describe all `total` trajectories in global order; device i keeps its shard and (re)allocates X, F, G for it */
+int  tolfg_multi_set_trajectories(tolfg_multi *m, long total, const tolfg_traj *trajs);
+int  tolfg_multi_shard(const tolfg_multi *m, int device_index, long *lo, long *hi);
+/* device pointers (on devices[device_index]) of the shard's rows, SNOPT layout, strides in elements of the batch dtype */
+int  tolfg_multi_buffers(const tolfg_multi *m, int device_index, void **dX, long *ldx, void **dF, long *ldf, void **dG, long *ldg);
+/* initial guesses of every trajectory, generated on the devices (ref: InitialCond with each trajectory's start) */
+int  tolfg_multi_x0(tolfg_multi *m);
+/* one evaluation of every shard: one launch per device, asynchronous */
+int  tolfg_multi_eval(tolfg_multi *m, int needF, int needG);
+/* ncclAllGather of the objectives over the devices, then waits for all of them; host_obj (optional): `total` values of
+ * the batch dtype in global trajectory order.  Reports a lost objective partial of any device (tolfg_batch_status). */
+int  tolfg_multi_gather_objectives(tolfg_multi *m, void *host_obj);
+/* Monte-Carlo mean of the objectives: one ncclAllReduce(sum) of the per-device partial sums */
+int  tolfg_multi_mean_objective(tolfg_multi *m, double *mean);
+int  tolfg_multi_sync(tolfg_multi *m);
+/* which librccl was loaded ("" before the first tolfg_multi_create) */
+const char *tolfg_multi_rccl_library(void);
+
+/* The sharding rule and the re-ordering of an all-gather's equally sized blocks into global trajectory order, for
+ * callers that run their own collectives (one process per GPU: tol_amd/distributed.py uses the same rule). */
+int  tolfg_shard_bounds(long total, int rank, int world, long *lo, long *hi);
+int  tolfg_compact_gathered(const void *padded, size_t elem_size, long total, int world, void *out);
+
 /* ------------------------------------------------------------------ misc */
 /* directory of the .param data shipped with the library (tol_amd/data) */
 const char *tolfg_default_root(void);

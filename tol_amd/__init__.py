@@ -6,6 +6,7 @@ buffers through torch, and the one-process-per-GPU batch driver.  There is no CP
 evaluation needs a gfx950 device and raises TolfgError otherwise.
 """
 from .capi import TolfgError, lib, lib_path   # noqa: F401
-from .host import Batch, Problem, Trajectory  # noqa: F401
+from . import capi                             # noqa: F401
+from .host import Batch, Multi, Problem, Trajectory  # noqa: F401
 
-__all__ = ["Batch", "Problem", "Trajectory", "TolfgError", "lib", "lib_path"]
+__all__ = ["Batch", "Multi", "Problem", "Trajectory", "TolfgError", "capi", "lib", "lib_path"]

@@ -107,6 +107,21 @@ SYMBOLS = {
     "tolfg_batch_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "tolfg_batch_kernel_time": (C.c_int, [C.c_void_p, _dp, _dp]),
     "tolfg_batch_algorithmic_bytes": (C.c_double, [C.c_void_p, C.c_int]),
+    "tolfg_multi_create": (C.c_int, [C.POINTER(BatchConfig), _ip, C.c_int, C.POINTER(C.c_void_p)]),
+    "tolfg_multi_destroy": (None, [C.c_void_p]),
+    "tolfg_multi_sizes": (C.c_int, [C.c_void_p, _ip, _ip, _ip]),
+    "tolfg_multi_set_trajectories": (C.c_int, [C.c_void_p, C.c_long, C.POINTER(Traj)]),
+    "tolfg_multi_shard": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_long), C.POINTER(C.c_long)]),
+    "tolfg_multi_buffers": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_long), C.POINTER(C.c_void_p),
+                                      C.POINTER(C.c_long), C.POINTER(C.c_void_p), C.POINTER(C.c_long)]),
+    "tolfg_multi_x0": (C.c_int, [C.c_void_p]),
+    "tolfg_multi_eval": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "tolfg_multi_gather_objectives": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "tolfg_multi_mean_objective": (C.c_int, [C.c_void_p, _dp]),
+    "tolfg_multi_sync": (C.c_int, [C.c_void_p]),
+    "tolfg_multi_rccl_library": (C.c_char_p, []),
+    "tolfg_shard_bounds": (C.c_int, [C.c_long, C.c_int, C.c_int, C.POINTER(C.c_long), C.POINTER(C.c_long)]),
+    "tolfg_compact_gathered": (C.c_int, [C.c_void_p, C.c_size_t, C.c_long, C.c_int, C.c_void_p]),
 }
 
 _lib = None

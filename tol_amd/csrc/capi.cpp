@@ -12,6 +12,7 @@
 
 #include "../../include/tolfg.h"
 #include "problem.h"
+#include "multi.h"
 
 using namespace tolfg;
 
@@ -21,6 +22,9 @@ struct tolfg_problem {
 };
 struct tolfg_batch {
     batch *b;
+};
+struct tolfg_multi {
+    multi *m;
 };
 
 namespace {
@@ -441,6 +445,118 @@ double tolfg_batch_algorithmic_bytes(const tolfg_batch *h, int B)
 {
     if (!h || B < 0) return 0.0;
     return h->b->algorithmic_bytes(B);
+}
+
+// ------------------------------------------------------------------------------------ several GPUs, one process
+
+int tolfg_multi_create(const tolfg_batch_config *cfg, const int *devices, int n_devices, tolfg_multi **out)
+{
+    if (!cfg || !out || !devices || n_devices < 1) return fail(TOLFG_ERR_ARG, "tolfg_multi_create: null argument or no device");
+    *out = nullptr;
+    return guarded([&] {
+        if (!cfg->mission || !cfg->aircraft || cfg->n_aircraft < 1)
+            throw std::invalid_argument("mission and at least one aircraft are required");
+        std::vector<std::string> names;
+        for (int i = 0; i < cfg->n_aircraft; ++i) {
+            if (!cfg->aircraft[i]) throw std::invalid_argument("null aircraft name");
+            names.emplace_back(cfg->aircraft[i]);
+        }
+        const std::string root = cfg->root_path ? std::string(cfg->root_path) : default_root();
+        *out = new tolfg_multi{new multi(cfg->mission, root, names, cfg->ts, cfg->windmodel, cfg->dtype, cfg->pattern,
+                                        std::vector<int>(devices, devices + n_devices))};
+    });
+}
+
+void tolfg_multi_destroy(tolfg_multi *h)
+{
+    if (!h) return;
+    delete h->m;
+    delete h;
+}
+
+int tolfg_multi_sizes(const tolfg_multi *h, int *n, int *neF, int *neG)
+{
+    if (!h) return fail(TOLFG_ERR_ARG, "null handle");
+    const Sizes &s = h->m->sizes();
+    if (n) *n = s.n;
+    if (neF) *neF = s.neF;
+    if (neG) *neG = s.neG;
+    return TOLFG_OK;
+}
+
+int tolfg_multi_set_trajectories(tolfg_multi *h, long total, const tolfg_traj *trajs)
+{
+    if (!h) return fail(TOLFG_ERR_ARG, "null handle");
+    return guarded([&] { h->m->set_trajectories(total, trajs); });
+}
+
+int tolfg_multi_shard(const tolfg_multi *h, int i, long *lo, long *hi)
+{
+    if (!h || !lo || !hi || i < 0 || i >= h->m->devices()) return fail(TOLFG_ERR_ARG, "tolfg_multi_shard: bad argument");
+    h->m->shard(i, lo, hi);
+    return TOLFG_OK;
+}
+
+int tolfg_multi_buffers(const tolfg_multi *h, int i, void **dX, long *ldx, void **dF, long *ldf, void **dG, long *ldg)
+{
+    if (!h || i < 0 || i >= h->m->devices()) return fail(TOLFG_ERR_ARG, "tolfg_multi_buffers: bad argument");
+    h->m->buffers(i, dX, ldx, dF, ldf, dG, ldg);
+    return TOLFG_OK;
+}
+
+int tolfg_multi_x0(tolfg_multi *h)
+{
+    if (!h) return fail(TOLFG_ERR_ARG, "null handle");
+    return guarded([&] { h->m->x0(); });
+}
+
+int tolfg_multi_eval(tolfg_multi *h, int needF, int needG)
+{
+    if (!h) return fail(TOLFG_ERR_ARG, "null handle");
+    return guarded([&] { h->m->eval(needF != 0, needG != 0); });
+}
+
+int tolfg_multi_gather_objectives(tolfg_multi *h, void *host_obj)
+{
+    if (!h) return fail(TOLFG_ERR_ARG, "null handle");
+    return guarded([&] { h->m->gather_objectives(host_obj); });
+}
+
+int tolfg_multi_mean_objective(tolfg_multi *h, double *mean)
+{
+    if (!h || !mean) return fail(TOLFG_ERR_ARG, "null argument");
+    return guarded([&] { *mean = h->m->mean_objective(); });
+}
+
+int tolfg_multi_sync(tolfg_multi *h)
+{
+    if (!h) return fail(TOLFG_ERR_ARG, "null handle");
+    return guarded([&] { h->m->sync(); });
+}
+
+const char *tolfg_multi_rccl_library(void)
+{
+    static std::string path;
+    try {
+        path = rccl_api::get().path;
+    } catch (const std::exception &) {
+        path.clear();
+    }
+    return path.c_str();
+}
+
+int tolfg_shard_bounds(long total, int rank, int world, long *lo, long *hi)
+{
+    if (total < 0 || world < 1 || rank < 0 || rank >= world || !lo || !hi) return fail(TOLFG_ERR_ARG, "tolfg_shard_bounds: bad argument");
+    shard_bounds(total, rank, world, lo, hi);
+    return TOLFG_OK;
+}
+
+int tolfg_compact_gathered(const void *padded, size_t elem_size, long total, int world, void *out)
+{
+    if (!padded || !out || elem_size == 0 || total < 0 || world < 1) return fail(TOLFG_ERR_ARG, "tolfg_compact_gathered: bad argument");
+    compact_gathered(padded, elem_size, total, world, out);
+    return TOLFG_OK;
 }
 
 }  // extern "C"

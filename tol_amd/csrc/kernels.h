@@ -131,6 +131,9 @@ hipError_t launch_fg(const FgArgs &a, int mission, int wind, int dtype, int vec,
 // dObj[t] = F[t*ldf]
 hipError_t launch_objectives(const void *F, long ldf, void *obj, int B, int dtype, hipStream_t s);
 
+// out[0] = sum of the B contiguous values at v, in double (v: elements of dtype)
+hipError_t launch_sum(const void *v, int B, int dtype, double *out, hipStream_t s);
+
 // Initial guess of B trajectories straight into device rows (ref: problemS10::InitialCond /
 // problemG7::InitialCond); bounds likewise (ref: problem::setLimits).  One-time set-up kernels.
 hipError_t launch_x0(const FgArgs &a, int mission, int dtype, hipStream_t s);

@@ -1094,6 +1094,20 @@ __global__ void objectives_kernel(const T *F, long ldf, T *obj, int B)
     if (t < B) obj[t] = F[(long)t * ldf];
 }
 
+// sum of B contiguous values in double, one workgroup (the per-device partial sum of a Monte-Carlo mean; B is a
+// few thousand at most, so a single 256-lane workgroup walking the vector is latency-, not bandwidth-bound)
+template <typename T>
+__global__ __launch_bounds__(256) void sum_kernel(const T *v, int B, double *out)
+{
+    __shared__ double part[4];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < B; i += 256) s += (double)v[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = part[0] + part[1] + part[2] + part[3];
+}
+
 template <typename T, int MISSION, int WIND, int PAT, int NP>
 hipError_t launch_vec(const FgArgs &a, int vec, dim3 grid, hipStream_t s, hipEvent_t t0, hipEvent_t t1)
 {
@@ -1359,6 +1373,13 @@ hipError_t launch_objectives(const void *F, long ldf, void *obj, int B, int dtyp
     else
         hipLaunchKernelGGL(objectives_kernel<float>, grid, block, 0, s, static_cast<const float *>(F), ldf,
                            static_cast<float *>(obj), B);
+    return hipGetLastError();
+}
+
+hipError_t launch_sum(const void *v, int B, int dtype, double *out, hipStream_t s)
+{
+    if (dtype == 0) hipLaunchKernelGGL(sum_kernel<double>, dim3(1), dim3(256), 0, s, static_cast<const double *>(v), B, out);
+    else            hipLaunchKernelGGL(sum_kernel<float>, dim3(1), dim3(256), 0, s, static_cast<const float *>(v), B, out);
     return hipGetLastError();
 }
 

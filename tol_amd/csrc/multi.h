@@ -1,0 +1,111 @@
+// multi.h -- one process, several MI355X: a batch of independent trajectories sharded over the devices of one node,
+// one launch stream and one issuing host thread per device, and the ONE collective the path has -- the all-gather of
+// the per-trajectory objectives -- through RCCL over xGMI (BASELINE north star).
+// No reference counterpart: tol solves one trajectory per process.
+#ifndef TOLFG_MULTI_H_
+#define TOLFG_MULTI_H_
+
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "problem.h"
+
+namespace tolfg {
+
+// Contiguous shard [lo, hi) of `total` trajectories for rank `rank` of `world`: the first total % world ranks get one
+// more (the rule of tol_amd/distributed.py::shard_bounds, so both host paths split a batch the same way).
+void shard_bounds(long total, int rank, int world, long *lo, long *hi);
+// widest shard = shard of rank 0
+long shard_width(long total, int world);
+// `padded` holds world blocks of `width` values, block r carrying rank r's shard in its first hi_r - lo_r places (what an
+// all-gather of equally sized buffers delivers); writes the `total` values in global trajectory order.
+void compact_gathered(const void *padded, size_t elem, long total, int world, void *out);
+
+// The RCCL entry points this library uses, resolved at run time (dlopen) so that libtolfg.so has no DT_NEEDED for
+// librccl, like it has none for the HIP runtime: a process must hold ONE copy of each, and which copy (PyTorch's
+// bundled one, /opt/rocm's) is the host program's choice.
+struct rccl_api {
+    void *handle = nullptr;
+    std::string path;
+    int (*GetVersion)(int *) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    int (*CommInitAll)(void **comms, int ndev, const int *devlist) = nullptr;
+    int (*CommDestroy)(void *comm) = nullptr;
+    int (*AllGather)(const void *send, void *recv, size_t sendcount, int datatype, void *comm, hipStream_t stream) = nullptr;
+    int (*AllReduce)(const void *send, void *recv, size_t count, int datatype, int op, void *comm, hipStream_t stream) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    static const rccl_api &get();          // throws hip_failure when no usable librccl is found
+};
+
+class multi {
+public:
+    // devices: HIP device ordinals, all different.  Communicators are created here (ncclCommInitAll).
+    multi(const std::string &mission, const std::string &root, const std::vector<std::string> &aircraft_names, int ts,
+          int windmodel, int dtype, int pattern, const std::vector<int> &devices);
+    ~multi();
+    multi(const multi &) = delete;
+    multi &operator=(const multi &) = delete;
+
+    int devices() const { return (int)dev_.size(); }
+    const Sizes &sizes() const { return part_[0].b->sizes(); }
+    long total() const { return total_; }
+    void shard(int i, long *lo, long *hi) const { *lo = part_.at(i).lo; *hi = part_.at(i).hi; }
+
+    // describe all `total` trajectories (global order); device i keeps [lo_i, hi_i); (re)allocates X, F, G there
+    void set_trajectories(long total, const tolfg_traj *trajs);
+    // device buffers of shard i: rows of the batch dtype in the SNOPT layout, strides in elements
+    void buffers(int i, void **dX, long *ldx, void **dF, long *ldf, void **dG, long *ldg) const;
+    // initial guesses of every shard, generated on its device
+    void x0();
+    // one evaluation of every shard: one launch per device, issued concurrently by the per-device host threads
+    void eval(bool needF, bool needG);
+    // all-gather of the objectives over the devices (RCCL, one group call), then wait for everything; out (optional):
+    // `total` values of the batch dtype in global trajectory order, copied from device 0
+    void gather_objectives(void *host_out);
+    // Monte-Carlo mean of the objectives: all-reduce(sum) of each device's partial sum (double)
+    double mean_objective();
+    // device pointer (device i) of the gathered, padded vector: devices() blocks of shard_width() values
+    const void *gathered(int i) const { return part_.at(i).dAll; }
+    void sync();
+    std::string rccl_path() const { return rccl_api::get().path; }
+
+private:
+    struct Part {
+        int device = 0;
+        long lo = 0, hi = 0;
+        std::unique_ptr<batch> b;
+        hipStream_t stream = nullptr;
+        void *dX = nullptr, *dF = nullptr, *dG = nullptr, *dObj = nullptr, *dAll = nullptr, *dSum = nullptr;
+        void *comm = nullptr;
+    };
+    std::vector<int> dev_;
+    std::vector<Part> part_;
+    int dtype_;
+    long total_ = 0, width_ = 0, ldx_ = 0, ldf_ = 0, ldg_ = 0;
+    size_t elem() const { return dtype_ == TOLFG_F64 ? 8 : 4; }
+    void free_buffers();
+    void release();
+
+    // one issuing thread per device beyond the first (the caller's thread serves device 0): launches reach the
+    // devices side by side instead of one hipSetDevice + launch after the other (8 devices: ~40 us serial)
+    void on_every_device(const std::function<void(Part &)> &fn);
+    void worker(int i);
+    std::vector<std::thread> threads_;
+    std::mutex mu_;
+    std::condition_variable cv_go_, cv_done_;
+    unsigned long generation_ = 0;
+    int pending_ = 0;
+    bool quit_ = false;
+    const std::function<void(Part &)> *job_ = nullptr;
+    std::vector<std::string> errors_;
+};
+
+}  // namespace tolfg
+#endif

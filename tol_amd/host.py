@@ -414,3 +414,99 @@ class Batch:
 
     def algorithmic_bytes(self, B=None):
         return lib().tolfg_batch_algorithmic_bytes(self._h, int(self.B if B is None else B))
+
+
+class Multi:
+    """One process, several GPUs (include/tolfg.h section 4): a batch sharded over `devices`, one launch per device,
+    the objectives gathered with ncclAllGather.  The device buffers belong to the library; fetch() copies a shard's F and
+    G to the host (tests, small batches)."""
+
+    def __init__(self, mission, aircraft=("tempest",), ts=0, windmodel=capi.WIND_SHEAR, dtype="f64", devices=(0,),
+                 root_path=None, pattern="reference"):
+        L = lib()
+        names = [a.encode() for a in aircraft]
+        arr = (C.c_char_p * len(names))(*names)
+        cfg = BatchConfig()
+        self._keep = (_enc(mission), _enc(root_path), arr, names)
+        cfg.mission, cfg.root_path = self._keep[0], self._keep[1]
+        cfg.aircraft, cfg.n_aircraft = arr, len(names)
+        cfg.ts, cfg.windmodel = int(ts), int(windmodel)
+        cfg.dtype = capi.F64 if dtype == "f64" else capi.F32
+        cfg.device = int(devices[0])
+        cfg.pattern = capi.PATTERNS[pattern]
+        devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+        self._h = C.c_void_p()
+        check(L.tolfg_multi_create(C.byref(cfg), devs, len(devices), C.byref(self._h)))
+        n, neF, neG = C.c_int(), C.c_int(), C.c_int()
+        check(L.tolfg_multi_sizes(self._h, C.byref(n), C.byref(neF), C.byref(neG)))
+        self.n, self.neF, self.neG = n.value, neF.value, neG.value
+        self.mission, self.dtype, self.devices = mission, dtype, tuple(int(d) for d in devices)
+        self.total = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().tolfg_multi_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def rccl_library(self):
+        return lib().tolfg_multi_rccl_library().decode()
+
+    def set_trajectories(self, trajs):
+        arr = (Traj * len(trajs))()
+        for t, tr in enumerate(trajs):
+            arr[t].aircraft, arr[t].Vref, arr[t].href = tr.aircraft, tr.Vref, tr.href
+            arr[t].mission = capi.MISSIONS[tr.mission] if self.mission == "mixed" else 0
+            arr[t].north_goal, arr[t].east_goal, arr[t].radius_goal = tr.north_goal, tr.east_goal, tr.radius_goal
+            arr[t].xi, arr[t].yi, arr[t].zi = tr.xi, tr.yi, tr.zi
+        check(lib().tolfg_multi_set_trajectories(self._h, len(trajs), arr))
+        self.total = len(trajs)
+
+    def shard(self, i):
+        lo, hi = C.c_long(), C.c_long()
+        check(lib().tolfg_multi_shard(self._h, int(i), C.byref(lo), C.byref(hi)))
+        return lo.value, hi.value
+
+    def x0(self):
+        check(lib().tolfg_multi_x0(self._h))
+
+    def eval(self, needF=True, needG=True):
+        check(lib().tolfg_multi_eval(self._h, int(needF), int(needG)))
+
+    def gather_objectives(self):
+        out = np.zeros(self.total, dtype=np.float64 if self.dtype == "f64" else np.float32)
+        check(lib().tolfg_multi_gather_objectives(self._h, out.ctypes.data))
+        return out
+
+    def mean_objective(self):
+        m = C.c_double()
+        check(lib().tolfg_multi_mean_objective(self._h, C.byref(m)))
+        return m.value
+
+    def sync(self):
+        check(lib().tolfg_multi_sync(self._h))
+
+    def fetch(self, i):
+        """(F, G) of shard i as host arrays [rows][ld] (device-to-host copies with the HIP runtime the library uses)."""
+        dX, dF, dG = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        ldx, ldf, ldg = C.c_long(), C.c_long(), C.c_long()
+        check(lib().tolfg_multi_buffers(self._h, int(i), C.byref(dX), C.byref(ldx), C.byref(dF), C.byref(ldf), C.byref(dG), C.byref(ldg)))
+        self.sync()
+        lo, hi = self.shard(i)
+        dt = np.float64 if self.dtype == "f64" else np.float32
+        out = []
+        hip = capi._hip_runtime
+        hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        hip.hipSetDevice(self.devices[i])
+        for ptr, ld in ((dF, ldf.value), (dG, ldg.value)):
+            a = np.zeros((hi - lo, ld), dtype=dt)
+            rc = hip.hipMemcpy(a.ctypes.data, ptr, a.nbytes, 2)       # hipMemcpyDeviceToHost
+            if rc != 0:
+                raise capi.TolfgError(capi.ERR_HIP, f"hipMemcpy failed with {rc}")
+            out.append(a)
+        return out[0], out[1]
