@@ -50,7 +50,12 @@ enum {
  * (src/problem.cpp:628-635,682-692).  v[(i*ny + j)*nz + k] is the value at east x0+i*dx, north
  * y0+j*dy, up z0+k*dz.  The aircraft's grid position is its NED position mapped to ENU plus
  * (east/north/up)_from_datum (ref: EastFromDatum..., src/problem.cpp:411-413).  Points outside
- * the grid are evaluated in the edge cell (the reference indexes out of bounds there). */
+ * the grid are evaluated in the edge cell (the reference indexes out of bounds there).
+ * nx != ny: the first index is the EAST index with its own extent nx, as the reference's cacheWind builds the cache
+ * (src/problem.cpp:437-441).  The reference's search loops bound the east index by the NORTH count and the north index
+ * by the east count (src/problem.cpp:556-566); inside the grid that changes nothing -- a loop that runs out of its
+ * bound ends on the index it would have stopped at -- and the reference-evaluated fixture holds a 5 x 3 x 4 case that
+ * this library reproduces; outside the grid the reference's reading is undefined and this library keeps the edge cell. */
 typedef struct tolfg_wind_grid {
     int    nx, ny, nz;        /* >= 2 each */
     double x0, y0, z0;

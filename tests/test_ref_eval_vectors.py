@@ -9,6 +9,15 @@ src/problem.cpp:1080-1186), wind model 3, non-shipped gains (kT, kp, kv, kdt all
 different, so G7's kp/kv mismatch and the S10 thrust terms are live), perturbed air-frame
 coefficients, non-zero start positions, every boundary row and gradient of both missions, the
 pattern, x0 and the bounds.  G entries the reference leaves uninitialised are NaN in the fixture.
+
+Round 3: the object the functions run on is built by the reference's OWN constructors (interpreted too: members from
+the class declarations, src/problem.cpp:13-192, then the mission constructor) -- the regenerated fixture's earlier
+arrays are bit-identical to round 2's, whose state had been typed in.  New points per case: windmodel code 199 = the
+linear boundary layer with seeded (Vref, href) in BASELINE configs[3]'s ranges, given to the reference as the model-99
+table its own case 1 would compute with those numbers (the product's shear-wind kernels take Vref, href themselves);
+code 4 = wind model 3 on a non-cubic 5 x 3 x 4 grid (the reference's index loops bound the east index by the north
+count and vice versa, src/problem.cpp:556-566: harmless inside the grid, where the product and the reference agree;
+outside it the reference indexes beyond its vectors and the product uses the edge cell -- documented, not compared).
 """
 import os
 
@@ -34,16 +43,30 @@ def case_ids():
     return load()[1]
 
 
-def oracle_problem(O, z, tag, windmodel=1, table=None, grid=False):
+def shear_of_point(z, tag, i):
+    """(Vref, href) of point i when it is a windmodel-199 point (the k-th such point uses row k of <tag>shear)."""
+    wm = z[tag + "windmodel"]
+    k = int(np.sum(wm[:i] == 199))
+    return tuple(float(v) for v in z[tag + "shear"][k])
+
+
+def grid_of(z, tag, kind):
+    key = "grid" if kind == 3 else "grid2"
+    geom = z[tag + key + "_geom"]
+    return dict(v=z[tag + key + "_v"], origin=tuple(geom[0:3]), spacing=tuple(geom[3:6]), datum=tuple(geom[6:9]))
+
+
+def oracle_problem(O, z, tag, windmodel=1, table=None, shear=None):
     mission = "S10" if int(z[tag + "meta"][0]) == 0 else "G7"
     N = int(z[tag + "meta"][1])
     east_goal, north_goal, _, radius = z[tag + "goal"]
     kw = {}
     if windmodel == 99:
         kw["wind_table"] = table
-    if grid:
-        geom = z[tag + "grid_geom"]
-        kw["wind_grid"] = dict(v=z[tag + "grid_v"], origin=tuple(geom[0:3]), spacing=tuple(geom[3:6]), datum=tuple(geom[6:9]))
+    if windmodel in (3, 4):
+        kw["wind_grid"] = grid_of(z, tag, windmodel)
+    if windmodel == 199:
+        kw["Vref"], kw["href"] = shear
     return O.Problem(mission, N=N, east_goal=east_goal, north_goal=north_goal, radius_goal=radius,
                      start=tuple(z[tag + "start"]), gains=z[tag + "gains"], ac15=z[tag + "ac15"], lim8=z[tag + "lim8"], **kw)
 
@@ -69,8 +92,13 @@ def test_oracle_F_and_G_match_the_reference_evaluation(oracle, tag):
     X, Fr, Gr, wm, wind = z[tag + "X"], z[tag + "F"], z[tag + "G"], z[tag + "windmodel"], z[tag + "wind"]
     worst = 0.0
     for i in range(len(X)):
-        p = oracle_problem(oracle, z, tag, int(wm[i]), wind[i], grid=int(wm[i]) == 3)
+        kind = int(wm[i])
+        p = oracle_problem(oracle, z, tag, kind, wind[i], shear=shear_of_point(z, tag, i) if kind == 199 else None)
         F, G = p.eval(X[i])
+        if kind == 199:     # the shear model with these (Vref, href) IS the table the reference was given
+            Ft, Gt = oracle_problem(oracle, z, tag, 99, wind[i]).eval(X[i])
+            assert_close(F, Ft, tol=1e-14, what="shear vs its table F")
+            assert_close(G, Gt, tol=1e-14, what="shear vs its table G")
         undefined = np.isnan(Gr[i])
         assert np.array_equal(undefined, p.undefined_mask()), "the reference's undefined entries are the 11 S10 boundary x dt slots"
         worst = max(worst, assert_close(F, Fr[i], tol=TOL_ORACLE, what=f"{tag} point {i} F"))
@@ -124,11 +152,11 @@ def test_hip_path_matches_the_reference_evaluation(tolfg, oracle, tmp_path, tag)
     east_goal, north_goal, up_goal, radius = z[tag + "goal"]
     start = tuple(float(v) for v in z[tag + "start"])
     X, Fr, Gr, wm, wind = z[tag + "X"], z[tag + "F"], z[tag + "G"], z[tag + "windmodel"], z[tag + "wind"]
-    geom = z[tag + "grid_geom"]
     for i in range(len(X)):
         kind = int(wm[i])
+        Vref, href = shear_of_point(z, tag, i) if kind == 199 else (2.4, 10.0)
         p = tolfg.Problem(mission, "fixture", east_goal=east_goal, north_goal=north_goal, up_goal=up_goal,
-                          radius_goal=radius, start=start, root_path=root,
+                          radius_goal=radius, start=start, root_path=root, Vref=Vref, href=href,
                           windmodel=tolfg.capi.WIND_SHEAR if kind != 99 else tolfg.capi.WIND_TABLE)
         if i == 0:
             assert (p.n, p.neF, p.neG) == tuple(int(v) for v in z[tag + "meta"][2:5])
@@ -140,8 +168,9 @@ def test_hip_path_matches_the_reference_evaluation(tolfg, oracle, tmp_path, tag)
             assert np.array_equal(Fl, z[tag + "Flow"]) and np.array_equal(Fu, z[tag + "Fupp"])
         if kind == 99:
             p.set_wind_table(wind[i])
-        elif kind == 3:
-            p.set_wind_grid(z[tag + "grid_v"], origin=tuple(geom[0:3]), spacing=tuple(geom[3:6]), datum=tuple(geom[6:9]))
+        elif kind in (3, 4):
+            g = grid_of(z, tag, kind)
+            p.set_wind_grid(g["v"], origin=g["origin"], spacing=g["spacing"], datum=g["datum"])
         if i == 0:
             # the four text dumps of a reference call (opt-in here): Woutput.txt must equal, byte for byte, what the
             # reference's modelWind wrote for this point (src/problem.cpp:740-756)
@@ -167,20 +196,32 @@ def test_hip_path_matches_the_reference_evaluation(tolfg, oracle, tmp_path, tag)
         assert_close(G, ref_G, mask=undefined, what=f"{tag} point {i} G (callback)")
         p.close()
 
-    # batched path: all shear-wind and table-wind points of the case in one launch each
-    for kind, wmodel in ((1, tolfg.capi.WIND_SHEAR), (99, tolfg.capi.WIND_TABLE)):
-        idx = np.flatnonzero(wm == kind)
-        bt = tolfg.Batch(mission, ("fixture",), ts=N, windmodel=wmodel, root_path=root)
-        bt.set_trajectories([tolfg.Trajectory(aircraft=0, Vref=2.4, href=10.0, north_goal=north_goal, east_goal=east_goal,
-                                              radius_goal=radius, xi=start[0], yi=start[1], zi=start[2]) for _ in idx])
-        dX, dF, dG = bt.alloc(len(idx))
-        dX[:, :bt.n] = torch.from_numpy(X[idx]).cuda()
-        dW = torch.from_numpy(np.ascontiguousarray(wind[idx])).cuda() if kind == 99 else None
-        bt.eval(dX, dF, dG, wind=dW)
-        torch.cuda.synchronize()
-        F, G = dF.cpu().numpy()[:, :bt.neF], dG.cpu().numpy()[:, :bt.neG]
-        for j, i in enumerate(idx):
-            undefined = np.isnan(Gr[i])
-            assert_close(F[j], Fr[i], what=f"{tag} point {i} F (batch)")
-            assert_close(G[j], np.where(undefined, 0.0, Gr[i]), mask=undefined, what=f"{tag} point {i} G (batch)")
-        bt.close()
+    # batched path: all shear-wind points (the reference's own 2.4 / 10 and the seeded per-trajectory (Vref, href) of the
+    # windmodel-199 points, side by side in one launch: the WIND_SHEAR kernels read the shear per trajectory) and all
+    # table-wind points of the case in one launch each; the shear launch also in fp32, per row class
+    from helpers import assert_close_f32
+    for kinds, wmodel in (((1, 199), tolfg.capi.WIND_SHEAR), ((99,), tolfg.capi.WIND_TABLE)):
+        idx = np.flatnonzero(np.isin(wm, kinds))
+        for dtype in (("f64", "f32") if wmodel == tolfg.capi.WIND_SHEAR else ("f64",)):
+            bt = tolfg.Batch(mission, ("fixture",), ts=N, windmodel=wmodel, root_path=root, dtype=dtype)
+            sh = [shear_of_point(z, tag, i) if int(wm[i]) == 199 else (2.4, 10.0) for i in idx]
+            bt.set_trajectories([tolfg.Trajectory(aircraft=0, Vref=sh[j][0], href=sh[j][1], north_goal=north_goal, east_goal=east_goal,
+                                                  radius_goal=radius, xi=start[0], yi=start[1], zi=start[2]) for j in range(len(idx))])
+            dX, dF, dG = bt.alloc(len(idx))
+            dX[:, :bt.n] = torch.from_numpy(X[idx]).to(bt.torch_dtype()).cuda()
+            dW = torch.from_numpy(np.ascontiguousarray(wind[idx])).cuda() if wmodel == tolfg.capi.WIND_TABLE else None
+            bt.eval(dX, dF, dG, wind=dW)
+            torch.cuda.synchronize()
+            F, G = dF.double().cpu().numpy()[:, :bt.neF], dG.double().cpu().numpy()[:, :bt.neG]
+            for j, i in enumerate(idx):
+                undefined = np.isnan(Gr[i])
+                if dtype == "f64":
+                    assert_close(F[j], Fr[i], what=f"{tag} point {i} F (batch)")
+                    assert_close(G[j], np.where(undefined, 0.0, Gr[i]), mask=undefined, what=f"{tag} point {i} G (batch)")
+                else:
+                    # float32 inputs: compare with the oracle at the rounded x (itself pinned to the reference above), per class
+                    kind = int(wm[i])
+                    po = oracle_problem(oracle, z, tag, kind, wind[i], shear=sh[j] if kind == 199 else None)
+                    Fo, Go = po.eval(dX[j, :bt.n].double().cpu().numpy())
+                    assert_close_f32(F[j], G[j], Fo, Go, z[tag + "iGfun"], N, mask=undefined, what=f"{tag} point {i} (batch f32)")
+            bt.close()

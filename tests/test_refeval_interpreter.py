@@ -103,3 +103,101 @@ def test_logic_ternary_and_libm(it):
     assert it.call(o, "logic", 2.0, 1.0) == 1.0 + math.pi
     assert it.call(o, "logic", 0.5, -3.0) == 0.25 - 3.0
     assert it.call(o, "logic", float("nan"), 0.0) == 1.0 + math.pi
+
+
+# ---- round 3: constructors, try / catch around an absent library, class declarations, big work arrays
+
+HDR = r'''
+class Base {
+public:
+    virtual ~Base();
+    void run(double x[]);
+    bool flag;
+protected:
+    Base(Args& a);
+    lib::Connection db;
+    const double g = 9.81;
+    int mode;
+    double a1, a2 = 2.5, a3;
+    std::string name;
+    std::vector<double> w, w2;
+    std::vector<std::vector<int>> nest;
+    int *idx;
+    double *buf;
+    struct Doc { public: Doc(double x) : x(x) {} double x; };
+    int count;
+};
+class Derived : public Base {
+public:
+    Derived(Args& a);
+protected:
+    void fill();
+    double extra;
+};
+'''
+CTORS = r'''
+Base::Base(Args& a): par(a.name), other(a.k)
+{
+    cout << "building " << a.name << endl;
+    flag = true;
+    name = a.name;
+    a1 = max(a.k, 1.0);
+    try {
+        cout << "connecting...";
+        lib::client::initialize();
+        db.connect("host:1");
+        mode = 3;
+    }
+    catch (exception& e) {
+        cout << "failure" << endl;
+        mode = 1;
+    }
+    if (a.name == "two") { a3 = 2; }
+    count = a.n * (a.n + 1);
+    w.resize(a.n + 1);
+    idx = new int[count];
+    buf = new double[a.n];
+    w2.resize(count);
+}
+Derived::Derived(Args& a) : Base(a) {
+    fill();
+}
+void Derived::fill() { for (int i = 0; i < count; i++) { idx[i] = i; } extra = a1 + a2 + w[0]; }
+int Base::direct() { lib::client::initialize(); return 1; }
+'''
+
+
+def test_class_declaration_gives_every_member_its_cpp_default():
+    m = cinterp.declare_members(HDR, "Base")
+    assert m["flag"] == 0 and m["mode"] == 0 and m["count"] == 0 and m["g"] == 9.81 and m["a2"] == 2.5 and m["name"] == ""
+    assert math.isnan(m["a1"]) and math.isnan(m["a3"])                       # uninitialised doubles
+    assert m["w"] == [] and m["w2"] == [] and m["nest"] == [] and m["idx"] == [] and m["buf"] == []
+    assert isinstance(m["db"], cinterp.Unavailable)
+    assert "run" not in m and "Doc" not in m and "x" not in m and "Base" not in m
+    assert cinterp.declare_members(HDR, "Derived") == pytest.approx({"extra": float("nan")}, nan_ok=True)
+    with pytest.raises(NameError):
+        cinterp.declare_members(HDR, "Missing")
+
+
+def test_constructors_run_base_first_and_an_absent_library_lands_in_the_catch_block():
+    it2 = cinterp.Interp([CTORS])
+    o = NS(_classes=["Derived", "Base"])
+    for cls in ("Base", "Derived"):
+        for k, v in cinterp.declare_members(HDR, cls).items():
+            setattr(o, k, v)
+    seen = []
+    it2.construct(o, "Derived", NS(name="two", k=0.25, n=3), between=lambda ob: seen.append((ob.mode, ob.count)))
+    assert seen == [(1, 12)]                        # the hook ran after Base::Base (catch block taken), before Derived's body
+    assert o.flag == 1 and o.name == "two" and o.mode == 1 and o.a1 == 1.0 and o.a3 == 2.0
+    assert o.w == [0.0] * 4 and o.w2 == [0.0] * 12 and o.idx == list(range(12)) and len(o.buf) == 3 and math.isnan(o.buf[0])
+    assert o.extra == 1.0 + 2.5 + 0.0
+    with pytest.raises(cinterp.ExternalUnavailable):        # outside a try block the absent library is an error, not a skip
+        it2.call(o, "direct")
+
+
+def test_huge_work_arrays_are_held_sparsely():
+    it2 = cinterp.Interp(["void K::big(int n) { a = new int[n]; v.resize(n); a[n - 1] = 7; v[5] = 2.5; }"])
+    o = NS(_classes=["K"], a=[], v=[])
+    it2.call(o, "big", cinterp.BIG + 10)
+    assert isinstance(o.a, cinterp.BigArray) and len(o.a) == cinterp.BIG + 10 and o.a[cinterp.BIG + 9] == 7 and o.a[3] == 0
+    assert isinstance(o.v, cinterp.BigArray) and o.v[5] == 2.5 and o.v[6] == 0.0 and o.v[4:7] == [0.0, 2.5, 0.0]

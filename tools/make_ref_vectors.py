@@ -64,58 +64,43 @@ def aircraft_members(v):
 
 
 class RefProblem:
-    """The members a constructed problemS10 / problemG7 holds (src/problem.cpp:13-192), as data."""
+    """A problemS10 / problemG7 object built the way the reference builds it: every data member the class declarations
+    hold (include/problem.h, include/problemG7.h: read at run time) starts at its C++ default -- NaN for an
+    uninitialised double -- and the reference's own constructors run on it (src/problem.cpp:13-192, then the mission's,
+    src/problemS10.cpp:9-13 / src/problemG7.cpp:9-13: setLimits(); InitialCond(); countG(x)).  The four parameter
+    members (ac, gn, lm, sn) are the numbers of the .param files; the database connection the constructor attempts is
+    not part of the interpreted sources, so the reference's own catch block selects wind model 1, as it does offline.
+    `start` other than (0, 0, 0) is a test hook: the reference hard-codes the start (src/problem.cpp:83-85), the hook
+    moves it between the base constructor and the mission constructor's body."""
 
-    def __init__(self, mission, N, ac, gains, lim, goal, start, lenG=None):
-        self._classes = ["problem" + mission, "problem"]
+    def __init__(self, it, mission, N, ac, gains, lim, goal, start, derived_body=True):
+        cls = "problem" + mission
+        self._classes = [cls, "problem"]
+        for header, c in (("problem.h", "problem"), (cls + ".h", cls)):
+            for name, val in cinterp.declare_members(open(os.path.join(REF, "include", header), errors="replace").read(), c).items():
+                setattr(self, name, val)
         nb = 11 if mission == "S10" else 12
+        # the .param members: values only (src/parameters.cpp:42-148 reads them from the files)
         self.sn = NS(ts=int(N), numinp=11, numstates=8, numbounds=nb, opt_tol=1e-6, feas_tol=1e-6)
         self.ac = ac
         self.gn = NS(kT=gains[0], kp=gains[1], kv=gains[2], ka=gains[3], kdt=gains[4])
-        # limit::limit, src/parameters.cpp:107-114
         self.lm = NS(dtmin=lim[0], dtmax=lim[1], xmin=lim[2], xmax=lim[3], ymin=lim[4], ymax=lim[5], zmin=lim[6], zmax=lim[7])
-        self.g, self.rho, self.pi = 9.81, 1.2682, math.pi                      # include/problem.h:72-74
         east_goal, north_goal, up_goal, radius = goal
-        self.yg, self.xg, self.zg, self.rg = float(east_goal), float(north_goal), -float(up_goal), float(radius)   # :24-27
-        self.mission = mission
-        self.xi, self.yi, self.zi = (float(s) for s in start)                  # :83-85 / :111-113 (0 in the reference)
-        if mission == "S10":                                                    # :80-106
-            self.Va1, self.Va2, self.gamma1, self.gamma2 = 4.0, 50.0, 0.0, 0.0
-            self.chi1, self.chi2 = -1.7453292519943296e+18, 1.7453292519943296e+18
-            self.phi1, self.phi2 = -1.5707963267948966, 1.5707963267948966
-        else:                                                                   # :108-134
-            self.Va1, self.Va2 = 4.0, 50.0
-            self.gamma1, self.gamma2 = 0.0 * math.pi / 180.0, 0.0 * math.pi / 180.0
-            self.chi1, self.chi2 = -1e20 * math.pi / 180.0, 1e20 * math.pi / 180.0
-            self.phi1, self.phi2 = -90.0 * math.pi / 180.0, 90.0 * math.pi / 180.0
-        self.CL1, self.CL2 = -0.5, 3.0
-        self.phidot1, self.phidot2 = -3.4906585039886591, 3.4906585039886591
-        self.CLdot1, self.CLdot2 = -200.0, 200.0
-        self.chi_d = 0.0                                                        # set by RotateYaw (G7)
-        T = N + 1
-        for name in ("u", "v", "w", "du_dx", "du_dy", "du_dz", "dv_dx", "dv_dy", "dv_dz", "dw_dx", "dw_dy", "dw_dz"):
-            setattr(self, name, [0.0] * T)                                      # :137-148
-        self.n = 11 * (N + 1) + 1                                               # :151
-        self.neF = 8 * N + 1 + nb                                               # :152
-        if lenG is None:
-            lenG = self.neF * self.n                                            # :159 (352 million at ts = 2000: the "long" set passes neG)
-        self.lenG = lenG
-        self.iGfun, self.jGvar = [0] * lenG, [0] * lenG
-        self.x, self.xlow, self.xupp = [0.0] * self.n, [0.0] * self.n, [0.0] * self.n
-        self.xmul, self.xstate = [0.0] * self.n, [0] * self.n
-        self.F, self.Flow, self.Fupp = [0.0] * self.neF, [0.0] * self.neF, [0.0] * self.neF
-        self.Fmul, self.Fstate = [0.0] * self.neF, [0] * self.neF
-        self.neG, self.neA = 0, 0                                               # :181-182
-        self.F_sparse, self.x_sparse = [0.0] * lenG, [0.0] * lenG               # :185-188 (vectors of double)
-        self.tf_sparse, self.tx_sparse = [0.0] * lenG, [0.0] * lenG
-        self.Gnonzero = 0
-        self.Pwindmodel = 1                                                     # offline fallback, :73-78
-        for name in ("Wx", "Wy", "Wz", "dWx_dx", "dWx_dy", "dWx_dz", "dWy_dx", "dWy_dy", "dWy_dz", "dWz_dx", "dWz_dy", "dWz_dz"):
-            setattr(self, name, 0.0)                                            # include/problem.h:99-102
-        # wind model 3 state (src/problem.cpp:371-460 fills it from MongoDB; synthetic here)
-        self.cache, self.cache_north, self.cache_east, self.cache_up = [], 0, 0, 0
-        self.xspacing = self.yspacing = self.zspacing = 150.0                   # include/problem.h:90-92
-        self.EastFromDatum = self.NorthFromDatum = self.UpFromDatum = 0.0
+        # what arguments::arguments(char**) unpacks from `0 0 100 <east_goal> <north_goal> <up_goal> <radius> <aircraft> <mission>`
+        # (src/arguments.cpp:36-46)
+        args = NS(east=0.0, north=0.0, up=100.0, east_goal=float(east_goal), north_goal=float(north_goal), up_goal=float(up_goal),
+                  radius_goal=float(radius), aircraft="fixture", mission=mission, root_path="./", stitch_previous=0)
+        start = tuple(float(v) for v in start)
+
+        def move_start(o):
+            if start != (0.0, 0.0, 0.0):
+                o.xi, o.yi, o.zi = start
+        if derived_body:
+            it.construct(self, cls, args, between=move_start)        # problem::problem, [hook], then setLimits / InitialCond / countG
+        else:
+            it.construct(self, "problem", args)                      # the "long" set: countG's probe is out of reach at ts = 2000
+            move_start(self)
+        assert self.Pwindmodel == 1                                   # the reference's catch block ran (src/problem.cpp:73-78)
 
     def set_wind_table(self, table):
         names = ("u", "v", "w", "du_dx", "du_dy", "du_dz", "dv_dx", "dv_dy", "dv_dz", "dw_dx", "dw_dy", "dw_dz")
@@ -128,9 +113,12 @@ class RefProblem:
         nx, ny, nz = v.shape
         self.cache = [[[NS(x=origin[0] + i * spacing[0], y=origin[1] + j * spacing[1], z=origin[2] + k * spacing[2],
                            u=0.0, v=float(v[i, j, k]), w=0.0) for k in range(nz)] for j in range(ny)] for i in range(nx)]
-        # the reference's search loops bound the x index by cache_north and the y index by cache_east
-        # (src/problem.cpp:556-572); a cubic grid makes the two readings coincide
-        self.cache_north, self.cache_east, self.cache_up = nx, ny, nz
+        # cacheWind builds cache[east index][north index][up index] with cache_east x cache_north x cache_up nodes
+        # (src/problem.cpp:437-441).  modelWind's search loops bound the FIRST index by cache_north and the second by
+        # cache_east (src/problem.cpp:556-566): on a cubic grid that makes no difference; on a non-cubic one the loops
+        # still stop in the right cell for every point inside the grid (a loop that runs out of its bound ends on the
+        # index it would have stopped at), and points outside it index beyond the vectors (undefined in the reference)
+        self.cache_east, self.cache_north, self.cache_up = nx, ny, nz
         self.xspacing, self.yspacing, self.zspacing = (float(s) for s in spacing)
         self.EastFromDatum, self.NorthFromDatum, self.UpFromDatum = (float(d) for d in datum)
         self.Pwindmodel = 3
@@ -172,16 +160,13 @@ def run_case(job):
     else:
         gains = np.array(read_param_values(os.path.join(REF, "problems", mission, "gains.param")))
         assert len(gains) == 5
-    o = RefProblem(mission, N, aircraft_members(ac15), gains, lim8, goal, start)
-    it.call(o, "InitialCond")
+    o = RefProblem(it, mission, N, aircraft_members(ac15), gains, lim8, goal, start)      # runs setLimits, InitialCond, countG(x)
     x0 = np.array(o.x)
-    it.call(o, "setLimits")
-    it.call(o, "countG", o.x)
     neG = o.neG
     out[tag + "meta"] = np.array([0 if mission == "S10" else 1, N, o.n, o.neF, neG])
     out[tag + "ac15"], out[tag + "gains"], out[tag + "lim8"] = ac15, gains, lim8
     out[tag + "goal"], out[tag + "start"] = np.array(goal), np.array(start)
-    out[tag + "chi_d"] = np.array([o.chi_d])
+    out[tag + "chi_d"] = np.array([getattr(o, "chi_d", 0.0)])      # problemG7 declares it; problemS10 has none
     out[tag + "x0"] = x0
     out[tag + "xlow"], out[tag + "xupp"] = np.array(o.xlow), np.array(o.xupp)
     out[tag + "Flow"], out[tag + "Fupp"] = np.array(o.Flow), np.array(o.Fupp)
@@ -201,6 +186,23 @@ def run_case(job):
             tbl[:3] *= 10.0
             points.append(("table", perturbed(x0, N, rng), tbl))
         points.append(("grid", perturbed(x0, N, rng), None))
+        # round 3: (a) the linear boundary layer with Vref, href other than the 2.4 / 10 the reference hard-codes
+        # (src/problem.cpp:504-505): handed to the reference as a model-99 table holding exactly what its case 1 would
+        # compute with those two numbers (v = -Vref zs / href, dv_dz = -Vref / href, zs = -z_NED: :520-524); the
+        # product's shear-wind kernels take (Vref, href) themselves.  (b) wind model 3 on a NON-cubic grid, 5 x 3 x 4.
+        shear_pts = []
+        for _ in range(3):
+            xs = perturbed(x0, N, rng)
+            Vref, href = float(rng.uniform(0.0, 5.0)), float(rng.uniform(5.0, 20.0))       # BASELINE configs[3]'s ranges
+            tbl = np.zeros((12, N + 1))
+            zs = -xs[1:].reshape(N + 1, 11)[:, 2]
+            tbl[1] = -Vref * zs / href
+            tbl[8] = -Vref / href
+            points.append(("sheartable", xs, tbl))
+            shear_pts.append((Vref, href))
+        grid2_v = rng.uniform(-6, 6, (5, 3, 4))
+        grid2 = dict(origin=(-260.0 + start[1], -240.0 + start[0], -30.0), spacing=(150.0, 150.0, 150.0), datum=(10.0, -20.0, 5.0))
+        points.append(("grid2", perturbed(x0, N, rng), None))
     else:
         points = [("shear", x0.copy(), None), ("shear", perturbed(x0, N, rng), None), ("none", perturbed(x0, N, rng), None)]
     X, Fs, Gs, kinds, tables, wouts = [], [], [], [], [], []
@@ -209,8 +211,10 @@ def run_case(job):
             o.Pwindmodel = 1
         elif pk == "none":
             o.Pwindmodel = 0                        # src/problem.cpp:477-492
-        elif pk == "table":
+        elif pk in ("table", "sheartable"):
             o.set_wind_table(tbl)
+        elif pk == "grid2":
+            o.set_grid(grid2_v, grid2["origin"], grid2["spacing"], grid2["datum"])
         else:
             o.set_grid(grid_v, grid["origin"], grid["spacing"], grid["datum"])
         xl = [float(t) for t in x]
@@ -220,7 +224,7 @@ def run_case(job):
         it.call(o, "computeF", xl, F)
         it.call(o, "computeG", xl, G)
         X.append(x); Fs.append(F); Gs.append(G)
-        kinds.append({"none": 0, "shear": 1, "table": 99, "grid": 3}[pk])
+        kinds.append({"none": 0, "shear": 1, "table": 99, "grid": 3, "sheartable": 199, "grid2": 4}[pk])
         tables.append(np.array([getattr(o, nm) for nm in WIND_NAMES]))
         wouts.append(it.output.files.get("Woutput.txt", ""))
     out[tag + "X"], out[tag + "F"], out[tag + "G"] = np.array(X), np.array(Fs), np.array(Gs)
@@ -230,6 +234,9 @@ def run_case(job):
         out[tag + "grid_v"] = grid_v
         out[tag + "grid_geom"] = np.array(list(grid["origin"]) + list(grid["spacing"]) + list(grid["datum"]))
         out[tag + "woutput0"] = np.frombuffer(wouts[0].encode(), dtype=np.uint8)   # Woutput.txt of the first point
+        out[tag + "shear"] = np.array(shear_pts)      # (Vref, href) of the windmodel-199 points, in order
+        out[tag + "grid2_v"] = grid2_v
+        out[tag + "grid2_geom"] = np.array(list(grid2["origin"]) + list(grid2["spacing"]) + list(grid2["datum"]))
     print("case %s %s N=%d %s: n=%d neF=%d neG=%d, %d points, %d interpreted calls, %.0f s" %
           (tag, mission, N, airframe, o.n, o.neF, neG, len(points), it.calls, time.time() - t_start), flush=True)
     return tag, out
@@ -299,10 +306,9 @@ def run_long(job):
     mission, N, airframe, goal, start, tag = (job[k] for k in ("mission", "N", "airframe", "goal", "start", "tag"))
     nb = 11 if mission == "S10" else 12
     # the decode rule against an interpreted countG
-    small = RefProblem(mission, 12, aircraft_members(np.array(read_param_values(os.path.join(REF, "aircraft", airframe + ".param")))),
+    small = RefProblem(it, mission, 12, aircraft_members(np.array(read_param_values(os.path.join(REF, "aircraft", airframe + ".param")))),
                        np.array(read_param_values(os.path.join(REF, "problems", mission, "gains.param"))),
                        np.array(read_param_values(os.path.join(REF, "problems", mission, "limits.param"))), goal, start)
-    it.call(small, "InitialCond"); it.call(small, "countG", small.x)
     iGs, jGs = closed_form_pattern(mission, 12)
     assert small.neG == len(iGs) and list(iGs) == small.iGfun[:small.neG] and list(jGs) == small.jGvar[:small.neG]
     dec = decode_pattern(iGs, jGs, small.neF, nb)
@@ -316,10 +322,12 @@ def run_long(job):
     gains = np.array(read_param_values(os.path.join(REF, "problems", mission, "gains.param")))
     iG, jG = closed_form_pattern(mission, N)
     neG = len(iG)
-    o = RefProblem(mission, N, aircraft_members(ac15), gains, lim8, goal, start, lenG=neG)
+    # problem::problem runs (its neF x n work arrays, 352 million entries each, are held sparsely: cinterp.BigArray); of the
+    # mission constructor's body, setLimits and InitialCond run, countG(x) is replaced by the closed form as explained
+    o = RefProblem(it, mission, N, aircraft_members(ac15), gains, lim8, goal, start, derived_body=False)
+    it.call(o, "setLimits")
     it.call(o, "InitialCond")
     x0 = np.array(o.x)
-    it.call(o, "setLimits")
     o.neG = neG
     o.iGfun, o.jGvar = [int(v) for v in iG], [int(v) for v in jG]
     o.F_sparse, o.x_sparse, o.tf_sparse, o.tx_sparse = decode_pattern(iG, jG, o.neF, nb)

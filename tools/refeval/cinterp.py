@@ -14,8 +14,14 @@ Supported: declarations of scalars and fixed arrays (with initialisers), assignm
 assignment, ++/--, arithmetic with C semantics (integer division truncates, % follows the dividend,
 int <-> double conversions on assignment and at calls), comparisons, && || !, ?:, casts, calls of
 other interpreted member functions and of libm, member access, indexing, if / else, for, while,
-switch / case / default / break, continue, return.  Statements the path does not depend on
-(`auto t = std::chrono...;`, `cout << ...;`) are skipped.  A scalar declared without an initialiser
+switch / case / default / break, continue, return, try / catch, constructors (the body; base-class
+constructors named in the initialiser list run first), `new T[n]`, vector resize / push_back / size / at.
+Statements the path does not depend on (`auto t = std::chrono...;`, `cout << ...;`) are skipped.  A call of
+something that is not in the interpreted sources and not libm (the MongoDB client the reference's constructor
+tries to reach) raises ExternalUnavailable, which an enclosing try / catch of the interpreted code handles like
+the exception the real library throws when there is no database -- so the reference's own catch block runs.
+declare_members() reads a class declaration from a header and gives every data member its C++ default (NaN for
+an uninitialised double).  A scalar declared without an initialiser
 reads as NaN, which is how the reference's uninitialised `Gs` shows up as "undefined" in the output.
 """
 import math
@@ -67,37 +73,155 @@ class Return(Exception):
         self.value = value
 
 
+class ExternalUnavailable(Exception):
+    """The interpreted code called into a library that is not part of the interpreted sources."""
+
+
+class Thrown(Exception):
+    """A `throw` statement of the interpreted code."""
+
+
+class Unavailable:
+    """Value of a data member whose class is not interpreted (mongo::DBClientConnection): any use is an external call."""
+    def __init__(self, what):
+        self.what = what
+
+    def __getattr__(self, name):
+        raise ExternalUnavailable("%s.%s" % (self.__dict__.get("what", "?"), name))
+
+
+class BigArray:
+    """`new T[n]` / vector.resize(n) for an n too large for a Python list (the reference's neF x n work arrays at
+    ts = 2000: 352 million entries, never touched on the path): elements are stored on first write."""
+    def __init__(self, n, fill):
+        self.n, self.fill, self.d = int(n), fill, {}
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self.d.get(k, self.fill) for k in range(*i.indices(self.n))]
+        return self.d.get(i, self.fill)
+
+    def __setitem__(self, i, v):
+        self.d[i] = v
+
+
+BIG = 40_000_000
+
+
+def new_array(n, fill):
+    return BigArray(n, fill) if n > BIG else [fill] * n
+
+
 class Function:
     def __init__(self, cls, name, rettype, params, body):
         self.cls, self.name, self.rettype, self.params, self.body = cls, name, rettype, params, body
 
 
+def _match_paren(text, i, open_ch, close_ch):
+    depth = 1
+    while depth and i < len(text):
+        depth += {open_ch: 1, close_ch: -1}.get(text[i], 0)
+        i += 1
+    return i
+
+
 def find_functions(text):
-    """{(class, name): (rettype, params_text, body_text)} for every `T Class::name(...) {...}` at top level."""
+    """{(class, name): (rettype, params_text, body_text)} for every `T Class::name(...) {...}` at top level, and for
+    every constructor `Class::Class(...) : inits {...}` its body under (class, class) plus the names its initialiser
+    list calls under (class, "<bases>")."""
     text = strip_comments(text)
     found = {}
-    for m in re.finditer(r"([A-Za-z_][\w:<>\*&\s]*?)\b(\w+)::(~?\w+)\s*\(", text):
-        # must be at brace depth 0
-        start = m.start()
-        if text.count("{", 0, start) != text.count("}", 0, start):
-            continue
-        i = m.end()
-        depth = 1
-        while depth and i < len(text):
-            depth += {"(": 1, ")": -1}.get(text[i], 0)
-            i += 1
-        params = text[m.end():i - 1]
-        j = i
-        while j < len(text) and text[j] not in "{;":
-            j += 1
-        if j >= len(text) or text[j] != "{" or ":" in text[i:j]:      # declarations and constructors are skipped
-            continue
-        k, depth = j + 1, 1
-        while depth and k < len(text):
-            depth += {"{": 1, "}": -1}.get(text[k], 0)
-            k += 1
-        found[(m.group(2), m.group(3))] = (m.group(1).strip(), params, text[j:k])
+    pats = [(r"([A-Za-z_][\w:<>\*&\s]*?)\b(\w+)::(~?\w+)\s*\(", False), (r"()\b(\w+)::(\2)\s*\(", True)]
+    for pat, ctor in pats:
+        for m in re.finditer(pat, text):
+            if (m.group(2) == m.group(3)) != ctor:
+                continue
+            start = m.start()
+            if text.count("{", 0, start) != text.count("}", 0, start):      # must be at brace depth 0
+                continue
+            i = _match_paren(text, m.end(), "(", ")")
+            params = text[m.end():i - 1]
+            j = i
+            while j < len(text) and text[j] not in "{;":
+                j += 1
+            if j >= len(text) or text[j] != "{":                          # a declaration
+                continue
+            inits = text[i:j]
+            if ":" in inits and not ctor:
+                continue
+            k = _match_paren(text, j + 1, "{", "}")
+            key = (m.group(2), m.group(3))
+            if key in found:
+                continue
+            found[key] = ("void" if ctor else m.group(1).strip(), params, text[j:k])
+            if ctor:
+                found[(m.group(2), "<bases>")] = re.findall(r"[:,]\s*(\w+)\s*\(", inits)
     return found
+
+
+def declare_members(header_text, cls):
+    """{member: default} of the data members `class cls { ... }` declares in header_text: double -> its initialiser or
+    NaN (uninitialised), int / bool -> initialiser or 0, std::string -> "", std::vector -> [], pointers -> [] (until a
+    `new`), members of other class types -> Unavailable.  Member functions, nested types and access labels are skipped."""
+    text = strip_comments(header_text)
+    m = re.search(r"\bclass\s+" + re.escape(cls) + r"\b[^;{]*\{", text)
+    if not m:
+        raise NameError("class %s is not declared in this header" % cls)
+    i, depth = m.end(), 1
+    while depth and i < len(text):
+        depth += {"{": 1, "}": -1}.get(text[i], 0)
+        i += 1
+    body = text[m.end():i - 1]
+    # drop nested struct / class bodies and inline function bodies
+    out, depth = [], 0
+    for ch in body:
+        if ch == "{":
+            depth += 1
+        elif ch == "}":
+            depth -= 1
+            if depth == 0:
+                out.append(";")
+            continue
+        if depth == 0:
+            out.append(ch)
+    members = {}
+    for stmt in "".join(out).split(";"):
+        stmt = re.sub(r"\b(public|protected|private)\s*:", " ", stmt).strip()
+        if not stmt or "(" in stmt.split("=")[0] or stmt.startswith(("struct", "class", "typedef", "using", "friend", "virtual")):
+            continue
+        stmt = re.sub(r"\b(const|static|mutable)\b", " ", stmt).strip()
+        mt = re.match(r"((?:std::)?[A-Za-z_][\w:]*(?:\s*<.*>)?)\s+(.*)$", stmt, re.S)
+        if not mt:
+            continue
+        ctype, decls = mt.group(1).strip(), mt.group(2)
+        for d in decls.split(","):
+            d = d.strip()
+            if not d:
+                continue
+            init = None
+            if "=" in d:
+                d, init = (t.strip() for t in d.split("=", 1))
+            ptr = d.startswith("*") or d.endswith("]")
+            name = d.strip("*& ").split("[")[0].strip()
+            if not re.fullmatch(r"[A-Za-z_]\w*", name):
+                continue
+            if ptr:
+                val = []
+            elif ctype in ("double", "float"):
+                val = NAN if init is None else float({"M_PI": math.pi}.get(init, init))
+            elif ctype in ("int", "bool", "long", "unsigned", "size_t", "short", "char"):
+                val = 0 if init is None else int({"true": 1, "false": 0}.get(init, init))
+            elif ctype in ("std::string", "string"):
+                val = ""
+            elif "vector" in ctype:
+                val = []
+            else:
+                val = Unavailable(name)
+            members[name] = val
+    return members
 
 
 class Parser:
@@ -244,6 +368,22 @@ class Parser:
             if v == "throw":
                 self.skip_to_semicolon()
                 return ("throw",)
+            if v == "try":
+                self.i += 1
+                self.expect("{")
+                body = self.parse_block_body()
+                self.expect("}")
+                handlers = []
+                while self.accept("catch"):
+                    self.expect("(")
+                    depth = 1
+                    while depth:                      # the exception declaration: not needed
+                        v2 = self.next()[1]
+                        depth += {"(": 1, ")": -1}.get(v2, 0)
+                    self.expect("{")
+                    handlers.append(self.parse_block_body())
+                    self.expect("}")
+                return ("try", body, handlers)
             if v == "cout" or (v == "std" and self.peek(2)[1] in ("cout", "cerr")) or v in ("auto", "delete"):
                 self.skip_to_semicolon()       # console output / chrono stopwatch: not on the path
                 return ("skip",)
@@ -384,6 +524,11 @@ class Parser:
                 return ("name", self.next()[1])
             if v in ("true", "false"):
                 return ("num", 1 if v == "true" else 0)
+            if self.peek()[1] == "::" and self.peek()[0] == "op":       # a qualified name: lib::ns::function
+                parts = [v]
+                while self.accept("::"):
+                    parts.append(self.next()[1])
+                return ("name", "::".join(parts))
             if v == "new":                          # new T[count]
                 base = self.parse_type()
                 self.expect("[")
@@ -451,7 +596,7 @@ class Interp:
             "sin": math.sin, "cos": math.cos, "tan": math.tan, "sqrt": lambda v: math.sqrt(v) if v >= 0 else NAN,
             "atan2": math.atan2, "atan": math.atan, "asin": math.asin, "acos": math.acos, "exp": math.exp,
             "log": math.log, "pow": _pow, "fabs": abs, "abs": abs, "floor": lambda v: float(math.floor(v)),
-            "ceil": lambda v: float(math.ceil(v)), "fmod": math.fmod,
+            "ceil": lambda v: float(math.ceil(v)), "fmod": math.fmod, "max": max, "min": min,
             "fopen": self._fopen, "fprintf": self._fprintf, "fclose": lambda fp: 0,
         }
         self.constants = {"M_PI": math.pi, "NULL": 0}
@@ -488,6 +633,26 @@ class Interp:
                 self.funcs[key] = f
                 return f
         return None
+
+    def construct(self, obj, cls, args, between=None):
+        """Run the constructor of class `cls` on `obj` the way C++ does: the base-class constructors its initialiser
+        list names first (members' own constructors are the caller's business: their values are data), then its body.
+        `between(obj)`, if given, runs after the base constructors and before the body (a test hook, e.g. to move the
+        start position the reference hard-codes)."""
+        for base in self.raw.get((cls, "<bases>"), []):
+            if (base, base) in self.raw:
+                self.construct(obj, base, args)
+        if between is not None:
+            between(obj)
+        f = self.function([cls], cls)
+        if f is None:
+            raise NameError("no interpreted constructor %s::%s" % (cls, cls))
+        self.calls += 1
+        frame = Frame(self, obj, [{f.params[0][0]: args} if f.params else {}], [{}])
+        try:
+            frame.exec_block(f.body, new_scope=False)
+        except Return:
+            pass
 
     def call(self, obj, name, *args):
         """Call member function `name` on `obj` (obj._classes = most-derived first)."""
@@ -527,6 +692,8 @@ class Frame:
             return getattr(self.obj, name)
         if name in self.it.constants:
             return self.it.constants[name]
+        if "::" in name:
+            raise ExternalUnavailable(name)
         raise NameError(name)
 
     def store_name(self, name, value):
@@ -660,7 +827,15 @@ class Frame:
         elif kind == "skip":
             pass
         elif kind == "throw":
-            raise RuntimeError("the interpreted code threw an exception")
+            raise Thrown("the interpreted code threw an exception")
+        elif kind == "try":
+            try:
+                self.exec_block(s[1])
+            except (ExternalUnavailable, Thrown):
+                # what the real library does when the service it needs is absent: throw; the first handler runs
+                if not s[2]:
+                    raise
+                self.exec_block(s[2][0])
         else:
             raise RuntimeError("statement %r" % (kind,))
 
@@ -772,6 +947,8 @@ class Frame:
                     return self.it.call(self.obj, name, *args)
                 if name in self.it.builtins:
                     return self.it.builtins[name](*args)
+                if "::" in name:
+                    raise ExternalUnavailable(name)
                 raise NameError("call of %s" % name)
             if fn[0] == "member":         # vector methods the path uses
                 o = self.eval(fn[1])
@@ -781,6 +958,16 @@ class Frame:
                     return o[c_int(args[0])]
                 if fn[2] == "push_back":
                     o.append(args[0])
+                    return None
+                if fn[2] == "resize":                  # std::vector<double>::resize(n): new elements are value-initialised (0.0)
+                    n2 = c_int(args[0])
+                    if n2 > BIG:
+                        self.assign_to(fn[1], BigArray(n2, 0.0))
+                    elif isinstance(o, list):
+                        del o[n2:]
+                        o.extend([0.0] * (n2 - len(o)))
+                    else:
+                        self.assign_to(fn[1], [0.0] * n2)
                     return None
             raise RuntimeError("call %r" % (fn,))
         if k == "postinc":
@@ -795,7 +982,7 @@ class Frame:
             v = self.eval(e[2])
             return float(v) if e[1] == "double" else c_int(v)
         if k == "newarr":
-            return [NAN if e[1] == "double" else 0] * c_int(self.eval(e[2]))
+            return new_array(c_int(self.eval(e[2])), NAN if e[1] == "double" else 0)
         if k == "comma":
             self.eval(e[1])
             return self.eval(e[2])
