@@ -10,6 +10,7 @@ enum { MISSION_S10 = 0, MISSION_G7 = 1, MISSION_MIXED = 2 };   // MIXED: every t
 enum { WIND_NONE = 0, WIND_SHEAR = 1, WIND_TABLE = 2, WIND_GRID = 3 };   // kernel-side enumeration
 enum { MAX_AIRCRAFT = 8 };
 enum { PATTERN_REFERENCE = 0, PATTERN_COMPACT = 1 };   // slab_table.h
+constexpr int kTileNodes = 64;                          // nodes per one-node-per-lane tile = wavefront width (kernels.hip TILE, plan.cpp)
 constexpr unsigned kEmptySlotWord = 0xFFFBADADu;        // fused path: every 32-bit word of an empty partial slot
 
 // Air-frame constants as the kernels want them (reciprocals taken once on the host).

@@ -49,7 +49,7 @@ namespace tolfg {
 
 namespace {
 
-constexpr int TILE = 64;           // nodes per dynamics tile = wavefront width
+constexpr int TILE = kTileNodes;    // nodes per dynamics tile = wavefront width (kernels.h)
 #ifndef TOLFG_MIN_WAVES_PER_SIMD
 #define TOLFG_MIN_WAVES_PER_SIMD 2  // register budget; the fp64 tile uses ~100 VGPRs, so this never binds
 #endif

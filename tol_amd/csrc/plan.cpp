@@ -4,10 +4,6 @@
 
 namespace tolfg {
 
-namespace {
-constexpr int kTileNodes = 64;     // nodes per dynamics tile = wavefront width (kTileNodes in kernels.hip)
-}
-
 void plan_tiles(int N, int dtype, int max_nt, int *tiles, int *nt)
 {
     // ceil(N/max_nt) tiles of equal size, the size rounded up to 4 nodes so that every tile's x window

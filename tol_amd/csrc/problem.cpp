@@ -104,18 +104,28 @@ batch::batch(const std::string &mission, const std::string &root, const std::vec
     }
 
     args_.pattern = pattern;
-    // measurement overrides of the launch plan (plan.cpp)
-    if (const char *e = std::getenv("TOLFG_WAVES_PER_CU")) { waves_per_cu_ = std::atoi(e); waves_forced_ = true; }
+    // measurement overrides of the launch plan (plan.cpp), clamped to what launch_fg accepts: a tile size is a multiple
+    // of 4 in [4, 64] (fp32: up to 128), a resident-wave cap lies in [0, 32], a tail count is not negative
+    auto env_int = [](const char *name, int lo, int hi, int *out) {
+        const char *e = std::getenv(name);
+        if (!e) return false;
+        const int v = std::atoi(e);
+        *out = v < lo ? lo : (v > hi ? hi : v);
+        return true;
+    };
+    auto tile_ok = [&](int v) { return v <= 0 ? 0 : std::min(std::max(v & ~3, 4), dtype == TOLFG_F32 ? 2 * kTileNodes : kTileNodes); };
+    int v = 0;
+    if (env_int("TOLFG_WAVES_PER_CU", 0, 32, &v)) { waves_per_cu_ = v; waves_forced_ = true; }
     args_.N = N;
     plan_tiles(N, dtype, 0, &args_.tiles, &args_.nt);      // eval() re-plans for its batch size
-    if (const char *e = std::getenv("TOLFG_TILE_NODES")) tile_nodes_forced_ = std::atoi(e);
-    if (const char *e = std::getenv("TOLFG_FUSED")) fused_forced_ = std::atoi(e) != 0;
-    if (const char *e = std::getenv("TOLFG_NT_STORES")) nt_forced_ = std::atoi(e) != 0;
-    if (const char *e = std::getenv("TOLFG_XCD")) xcd_forced_ = std::atoi(e) != 0;
-    if (const char *e = std::getenv("TOLFG_STAGGER")) stagger_forced_ = std::atoi(e) != 0;
+    if (env_int("TOLFG_TILE_NODES", 0, 2 * kTileNodes, &v)) tile_nodes_forced_ = tile_ok(v);
+    if (env_int("TOLFG_FUSED", 0, 1, &v)) fused_forced_ = v;
+    if (env_int("TOLFG_NT_STORES", 0, 1, &v)) nt_forced_ = v;
+    if (env_int("TOLFG_XCD", 0, 1, &v)) xcd_forced_ = v;
+    if (env_int("TOLFG_STAGGER", 0, 1, &v)) stagger_forced_ = v;
     if (const char *e = std::getenv("TOLFG_TAIL")) {        // "count:nt", count 0 = no tail
-        tail_forced_ = std::atoi(e);
-        if (const char *c = std::strchr(e, ':')) tail_nt_forced_ = std::atoi(c + 1);
+        tail_forced_ = std::max(0, std::atoi(e));
+        if (const char *c = std::strchr(e, ':')) tail_nt_forced_ = std::min(tile_ok(std::atoi(c + 1)), kTileNodes);
     }
     for (int m = 0; m < 2; ++m) {
         const gain &g = gains(m);
