@@ -38,9 +38,10 @@ LaunchPlan plan_launch(const LaunchShape &sh)
     //    B=512: 23.8 vs 31.1 us) and want every wave that fits, so no cap.  All the launch's waves are then resident
     //    from the start and would run in step (load, then compute four to a SIMD, and only then the first store):
     //    from 12 waves per CU on, the waves take an issue priority from their slot on the SIMD (FgArgs::stagger), which
-    //    lets one wave per SIMD run ahead of the next: B=1024 fp64 43.7 -> 41.3 us, mixed fp64 45.4 -> 42.5, mixed fp32
-    //    2048 44.7 -> 40.4; nothing at 2 to 8 waves per CU (B <= 512) and nothing beyond the cache, where the waves
-    //    are out of step anyway.
+    //    lets one wave per SIMD run ahead of the next.  Alternating on/off on the SAME buffers (profiles/r03_plan.md):
+    //    B=1024 fp64 43.5 -> 43.1 us, mixed fp64 42.0 -> 41.5, mixed fp32 2048 44.1 -> 43.6: 1-1.5 %, never slower; nothing
+    //    at <= 8 waves per CU and nothing beyond the cache, where the waves are out of step anyway.  (A first A/B across
+    //    two processes read 5-10 %: that was the allocation-to-allocation spread of these shapes, +-2 %.)
     //  * tiles are dealt to the XCDs in contiguous eighths (+1...+8 %, never slower).
     LaunchPlan p{};
     const bool beyond_cache = sh.out_bytes > 192.0 * 1024 * 1024;
