@@ -253,9 +253,11 @@ int  tolfg_batch_bounds_device(tolfg_batch *b, int B, void *dXlow, void *dXupp, 
 int  tolfg_batch_bounds(const tolfg_batch *b, int t, double zi,
                         double *xlow, double *xupp, double *Flow, double *Fupp);
 
-/* Stream contract: a batch owns per-launch workspace (objective partials, arrival counters), so its
- * evaluations must be issued on ONE stream at a time, and a stream synchronisation must separate the last
- * evaluation from tolfg_batch_set_trajectories / tolfg_batch_set_wind_grid (they copy on the null stream).
+/* Stream contract: a batch owns per-launch workspace (objective partials, arrival counters), so its evaluations run one
+ * at a time.  Evaluations issued on ONE stream are ordered by the stream; when an evaluation names a different stream than
+ * the one before it, the library drains the previous stream first (blocking: use one stream per batch, several batches for
+ * several streams).  A stream synchronisation must separate the last evaluation from tolfg_batch_set_trajectories /
+ * tolfg_batch_set_wind_grid (they copy on the null stream).
  * The first evaluation of a batch (and one with a larger B than before) allocates and uploads; do not
  * issue it inside a hipGraph capture -- warm up once, then capture (tests/test_gpu_parity.py does). */
 /* Evaluate F and G of trajectories [0,B) in one launch.  dX, dF, dG, dWind are DEVICE pointers to

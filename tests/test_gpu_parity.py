@@ -329,3 +329,29 @@ def test_callback_with_the_callers_own_arrays_kept_across_calls(tolfg, oracle, m
         assert_close(G, np.where(o.undefined_mask(), 0.0, Go), mask=o.undefined_mask(), what=f"call {call} G")
         assert p.registered_arrays() == (0 if call == 0 else (3 if p.n % 2 == 0 else 2))
     p.close()
+
+
+def test_a_batch_moved_between_streams_keeps_its_evaluations_apart(tolfg, oracle):
+    """Stream contract: the per-launch workspace belongs to one evaluation at a time.  A caller that alternates between
+    two streams without synchronising gets the ordering enforced by the library (the previous stream is drained first):
+    every evaluation's objective must be right -- a race on the partial slots or arrival counters would show there."""
+    import torch
+    N, B = 200, 64
+    bt = tolfg.Batch("S10", ["tempest"], ts=N)
+    bt.set_trajectories([tolfg.Trajectory(Vref=0.1 * t) for t in range(B)])
+    dX, dF, dG = bt.alloc(B)
+    bt.x0_device(dX)
+    bt.eval(dX, dF, dG)
+    torch.cuda.synchronize()
+    want = dF[:, :bt.neF].clone()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    outs = [bt.alloc(B)[1:] for _ in range(2)]
+    for i in range(24):
+        with torch.cuda.stream(streams[i & 1]):
+            outs[i & 1][0].zero_()
+            bt.eval(dX, outs[i & 1][0], outs[i & 1][1])
+    torch.cuda.synchronize()
+    bt.status()
+    for F, _ in outs:
+        assert torch.equal(F[:, :bt.neF], want)
+    bt.close()

@@ -284,6 +284,18 @@ void batch::eval(int B, const void *dX, long ldx, void *dF, long ldf, void *dG, 
     if (windmodel_ == TOLFG_WIND_TABLE && !dWind) throw std::invalid_argument("eval: table wind needs dWind");
     if (windmodel_ == TOLFG_WIND_GRID && !d_grid_) throw std::invalid_argument("eval: grid wind needs tolfg_*_set_wind_grid");
     if (!uploaded_) upload();
+    // Stream contract (include/tolfg.h): the per-launch workspace (objective partials, arrival counters) belongs to ONE
+    // evaluation at a time.  Evaluations on one stream are ordered by the stream; a caller that moves to another stream
+    // gets the ordering enforced here -- the previous stream is drained first (a rare, blocking event, no cost otherwise).
+    // (Not while `stream` is being captured into a hipGraph: nothing executes then, and a synchronisation would break the
+    // capture; the caller warmed up and synchronised before capturing, as the header asks.)
+    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &capturing) != hipSuccess) { capturing = hipStreamCaptureStatusNone; clear_errors(); }
+    if (capturing == hipStreamCaptureStatusNone) {
+        if (have_last_stream_ && stream != last_stream_) check(hipStreamSynchronize(last_stream_), "hipStreamSynchronize(previous stream)");
+        last_stream_ = stream;
+        have_last_stream_ = true;
+    }
     if (take_lost_partial())
         throw hip_failure("an earlier evaluation of this batch lost an objective partial: its F[0] is not a number (does x carry "
                           "NaNs?); the outputs of that evaluation must not be used");

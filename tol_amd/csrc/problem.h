@@ -109,6 +109,8 @@ private:
     int xcd_forced_ = -1;               // TOLFG_XCD=0/1 overrides the tile order (measurements)
     int stagger_forced_ = -1;           // TOLFG_STAGGER=0/1 overrides the issue-priority stagger (measurements)
     int ntraj_ = 0, cap_ = 0;
+    hipStream_t last_stream_ = nullptr;  // stream of the last evaluation: moving to another one drains it first (stream contract)
+    bool have_last_stream_ = false;
     bool uploaded_ = false;
     TrajDev *d_traj_ = nullptr;
     std::vector<tolfg_traj> host_traj_;
