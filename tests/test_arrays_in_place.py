@@ -104,7 +104,10 @@ MARKER = np.array([0xFFFBADADFFFBADAD], dtype=np.uint64).view(np.float64)[0]    
 def test_lost_partial_is_reported_by_the_batch(tolfg):
     """A thrust value that IS the empty-slot marker (a NaN with that payload) makes its tile's objective partial look
     like an empty slot for good: the launch must end by itself, and the host must be told."""
+    import os
     import torch
+    if os.environ.get("TOLFG_FUSED") == "0":
+        pytest.skip("the two-launch form (a measurement override) has no polled slots: nothing can be lost there")
     N, B = 200, 12               # more than 8 trajectories: the tile-per-workgroup path with its polled partial slots
     bt = tolfg.Batch("S10", ["tempest"], ts=N)
     bt.set_trajectories([tolfg.Trajectory() for _ in range(B)])
