@@ -626,6 +626,22 @@ __device__ __forceinline__ void tile_body(const FgArgs &a, T *lds, int item, int
     T *Frow = static_cast<T *>(a.F) + (long)b * a.ldf;
     T *Grow = static_cast<T *>(a.G) + (long)b * a.ldg;
 
+    const TrajDev tr = a.traj[b];
+    // the trajectory's mission: a template constant, or (mixed batch) wave-uniform from its record
+    const int ms = MISSION == MISSION_MIXED ? __builtin_amdgcn_readfirstlane(tr.mission) : MISSION;
+    // The slab stream's per-lane offsets (SlabStream) are asked for FIRST, the x window right behind them: both are then
+    // in flight together, and the one wait before the window's LDS writes covers both (loads return in order).  Asked
+    // for after the window, they were issued only once the window had arrived: a second memory latency on every wave's
+    // critical path.
+    SlabStream<T, PAT, NT, TN> stream;
+#if defined(TOLFG_STAMPS) || defined(TOLFG_ABLATE)
+    const bool late_table = TOLFG_VARIANT(a) & 8192;       // A/B: round-3's first order (offsets asked for after the window)
+#else
+    constexpr bool late_table = false;
+#endif
+    if (a.needG && !late_table) stream.load(Grow + a.c0[ms] + (long)SLABN * k0, lane);
+    const T dt = xrow[0];
+
     // ---- x window = x[11*k0 .. 11*(k0+cnt)+9): one element before node k0 (keeps the start 16-byte
     // aligned) up to the 8 states of node k0+cnt, rounded up to whole vectors (stays inside the row);
     // contiguous 16-byte loads -> LDS -> this lane's node(s) (transpose)
@@ -651,13 +667,7 @@ __device__ __forceinline__ void tile_body(const FgArgs &a, T *lds, int item, int
             if (i < nvec) *reinterpret_cast<vec *>(lds + i * VEC) = win[j];
         }
     }
-    const TrajDev tr = a.traj[b];
-    // the trajectory's mission: a template constant, or (mixed batch) wave-uniform from its record
-    const int ms = MISSION == MISSION_MIXED ? __builtin_amdgcn_readfirstlane(tr.mission) : MISSION;
-    const T dt = xrow[0];
-    // the slab stream's per-lane offsets travel with the window (SlabStream)
-    SlabStream<T, PAT, NT, TN> stream;
-    if (a.needG) stream.load(Grow + a.c0[ms] + (long)SLABN * k0, lane);
+    if (a.needG && late_table) stream.load(Grow + a.c0[ms] + (long)SLABN * k0, lane);
     __syncthreads();
     TOLFG_STAMP(a, 1);
     bool act[NP];

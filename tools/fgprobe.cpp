@@ -81,7 +81,7 @@ int main(int argc, char **argv)
 
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    if (variant & 8192) a.needF = 0;
+    if (variant & 32768) a.needF = 0;
     for (int i = 0; i < 5; i++) CK(tolfg::launch_fg(a, tolfg::MISSION_S10, tolfg::WIND_SHEAR, 0, 2, nullptr));
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0));
