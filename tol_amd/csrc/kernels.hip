@@ -465,6 +465,10 @@ template <typename T, int PAT, bool NT, int TN> struct SlabStream {
     static constexpr int RMAX = (TN * SLABN + GV - 1) / (TILE * GV) + 1;   // rounds a full tile needs at most
     static constexpr int PU = P < RMAX ? P : RMAX;                         // table rounds actually used
     static constexpr int CHU = ((PU * GV + 1) / 2 + 3) / 4;
+#ifndef TOLFG_STREAM_AHEAD
+#define TOLFG_STREAM_AHEAD 1
+#endif
+    static constexpr int AHEAD = TOLFG_STREAM_AHEAD < RMAX ? TOLFG_STREAM_AHEAD : 1;     // rounds of LDS reads in flight ahead of the store
     u4 tb[CHU];
     T *gslab;
     int shift;             // the region starts `shift` elements past a 16-byte boundary: wave-uniform
@@ -501,18 +505,19 @@ template <typename T, int PAT, bool NT, int TN> struct SlabStream {
         const int qhi = (E + shift) / GV;                  // whole vectors are q in [shift ? 1 : 0, qhi)
         const char *lb = reinterpret_cast<const char *>(lds);
         vec *gp = reinterpret_cast<vec *>(gslab - shift) + lane;
-        // one round ahead: the LDS reads of round R + 1 are in flight while round R's vector is stored (a wave
-        // alone on its SIMD -- small batches, the SNOPT callback -- otherwise pays the LDS latency once per round)
-        vec cur = gather(lb, 0);
+        // AHEAD rounds ahead: the LDS reads of rounds R + 1 .. R + AHEAD are in flight while round R's vector is stored (a
+        // wave alone on its SIMD -- small batches, the SNOPT callback -- otherwise pays the LDS latency once per round)
+        vec q[AHEAD];
+#pragma unroll
+        for (int d = 0; d < AHEAD; d++) q[d] = gather(lb, d);
 #pragma unroll
         for (int R = 0; R < RMAX; R++) {
             if (TILE * R >= qhi) break;                    // wave-uniform
-            vec nxt = cur;
-            if (R + 1 < RMAX) nxt = gather(lb, R + 1);
-            const int q = TILE * R + lane;
+            const vec cur = q[R % AHEAD];
+            if (R + AHEAD < RMAX) q[R % AHEAD] = gather(lb, R + AHEAD);
+            const int qv = TILE * R + lane;
             const bool whole = R > 0 && TILE * (R + 1) <= qhi;     // wave-uniform: no lane is cut off
-            if (whole || (q < qhi && (R > 0 || shift == 0 || lane > 0))) stream_store<NT>(gp + TILE * R, cur);
-            cur = nxt;
+            if (whole || (qv < qhi && (R > 0 || shift == 0 || lane > 0))) stream_store<NT>(gp + TILE * R, cur);
         }
         // the elements before the first and after the last whole vector
         const int ntail = E + shift - qhi * GV;            // in [0, GV)
