@@ -3,7 +3,8 @@
 // One evaluation produces F and G of a batch of trajectories.  Work decomposition:
 //
 //   * a TILE is up to 64 consecutive collocation nodes of one trajectory, one wavefront, lane = node
-//     (tile_body).  Per node it produces the defects F[8k+1..8k+8], the node's contiguous Jacobian
+//     (tile_body); the packed fp32 kernels (NP = 2) put two nodes on a lane -- a pair of floats per
+//     register pair, v_pk_*_f32 arithmetic -- and a tile is then up to 128 nodes.  Per node it produces the defects F[8k+1..8k+8], the node's contiguous Jacobian
 //     slab (104 entries, or 46 in the compact pattern), its objective-gradient entries and its
 //     objective terms (ref: problem::dynamicConstraints src/problem.cpp:929-1021,
 //     problem::dynamicsGradients src/problem.cpp:1035-1208, wind models 0/1/3 src/problem.cpp:480-695,
@@ -19,7 +20,8 @@
 //     measured 5-10 % slower.  Tiles are dealt to the 8 XCDs in contiguous eighths.  When the outputs
 //     exceed the Infinity Cache the launch requests more LDS than a tile uses to cap the resident
 //     waves per CU (the kernel is bound by the HBM write path, which serves fewer concurrent store
-//     streams better) and the slab stream is non-temporal; when they fit, plain stores and no cap.
+//     streams better) and the slab stream is non-temporal; when they fit, plain stores, no cap, and the
+//     waves take issue priorities from their SIMD slots so that they do not run in step (FgArgs::stagger).
 //   * callback path (a few short trajectories): fg_single_kernel, whole trajectory per workgroup,
 //     one launch, optional completion word for the spinning host.
 //   * a mixed batch (MISSION_MIXED) reads each trajectory's mission from its record; a tile is one
@@ -29,8 +31,9 @@
 //     loads and transposed through LDS, and the slabs (83 % of all bytes) are written with
 //     contiguous 16-byte stores, 1 KiB per wave instruction.  Of the 104 slab elements
 //     only 32 are computed per node; the 58 structural zeros and the +-1 constants are injected from
-//     a compile-time table while streaming out, so the LDS exchange is 35 elements per node
-//     (17.9 KB per wave in fp64).  F (64 B per node) and the objective-gradient entries (24 B per
+//     a compile-time table while streaming out (SlabStream: per-lane LDS offsets from the kStream table,
+//     loaded with the x window), so the LDS exchange is 35 elements per node (14.8 KB per wave at ts = 200
+//     in fp64).  F (64 B per node) and the objective-gradient entries (24 B per
 //     node) go straight from registers: every lane's piece is contiguous with its neighbour's, so
 //     whole lines are completed inside L2 by consecutive instructions of the same wave.
 //   * air-frame coefficients and per-trajectory constants are wave-uniform: they arrive through
