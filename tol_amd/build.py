@@ -8,7 +8,7 @@ LIB = os.path.join(HERE, "lib", "libtolfg.so")
 
 
 def build(force=False):
-    args = ["make", "-s", "-j4", "-C", CSRC]      # kernels.hip is two translation units: they build in parallel
+    args = ["make", "-s", "-j4", "-C", CSRC]      # kernels.hip is three translation units: they build in parallel
     if force:
         args.append("-B")
     subprocess.run(args, check=True)
