@@ -371,18 +371,17 @@ def sharded_run(tol_amd, job, mission, aircraft, ts, dtype, pattern, per_gpu, gl
     # tolfg_batch_set_timing; rocprofv3 --kernel-trace turns the same dispatch profiling on): per-launch durations, but
     # each launch then takes 10-16 us longer, part of it inside the reported duration (profiles/r02_event_cost.md).
     inst_ms = inst_min_ms = inst_step_ms = 0.0
-    if instrumented and B > 0:
-        bt.set_timing(True)
+    if instrumented:          # every rank runs the same steps (a rank with an empty shard still takes part in the gathers)
+        bt.set_timing(B > 0)
         t1 = time.perf_counter()
         for i in range(steps):
             step(i)
         fence()
         inst_step_ms = 1e3 * (time.perf_counter() - t1) / steps
-        nlaunch, inst_ms, inst_min_ms = bt.kernel_time()
+        if B > 0:
+            nlaunch, inst_ms, inst_min_ms = bt.kernel_time()
+            assert nlaunch == steps
         bt.set_timing(False)
-        assert nlaunch == steps
-    elif instrumented:
-        fence()
     elapsed, kern_ms, gather_us = job.max_over_ranks([elapsed, kern_ms, gather_us])
     out.update(elapsed=elapsed, kern_ms=kern_ms, gather_us=gather_us, inst_ms=inst_ms, inst_min_ms=inst_min_ms, inst_step_ms=inst_step_ms,
                alg_bytes=bt.algorithmic_bytes(B) if B > 0 else 0.0)
