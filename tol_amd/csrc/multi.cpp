@@ -21,6 +21,13 @@ void check(hipError_t e, const char *what)
     }
 }
 
+// the calling thread's current device is the caller's business: put it back whatever this library selected meanwhile
+struct DeviceGuard {
+    int prev = -1;
+    DeviceGuard() { if (hipGetDevice(&prev) != hipSuccess) prev = -1; }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
 // rccl.h: ncclFloat32 = 7, ncclFloat64 = 8, ncclSum = 0, ncclSuccess = 0 (/opt/rocm/include/rccl/rccl.h:448-467)
 enum { kNcclFloat32 = 7, kNcclFloat64 = 8, kNcclSum = 0 };
 
@@ -123,6 +130,7 @@ multi::multi(const std::string &mission, const std::string &root, const std::vec
         p.b.reset(new batch(mission, root, names, ts, windmodel, dtype, devices[i], pattern));   // host-side set-up only
     }
     // device state: needs the GPUs (no CPU path)
+    DeviceGuard guard;
     try {
         int ndev = 0;
         check(hipGetDeviceCount(&ndev), "hipGetDeviceCount");
@@ -148,6 +156,7 @@ multi::~multi() { release(); }
 
 void multi::release()
 {
+    DeviceGuard guard;
     {
         std::lock_guard<std::mutex> lk(mu_);
         quit_ = true;
@@ -176,6 +185,7 @@ void multi::release()
 
 void multi::free_buffers()
 {
+    DeviceGuard guard;
     for (Part &p : part_) {
         (void)hipSetDevice(p.device);
         for (void **q : {&p.dX, &p.dF, &p.dG, &p.dObj, &p.dAll}) {
@@ -215,6 +225,7 @@ void multi::worker(int i)
 
 void multi::on_every_device(const std::function<void(Part &)> &fn)
 {
+    DeviceGuard guard;
     {
         std::lock_guard<std::mutex> lk(mu_);
         job_ = &fn;
@@ -311,6 +322,7 @@ void multi::gather_objectives(void *host_out)
     for (Part &p : part_)
         if (p.b->take_lost_partial()) throw hip_failure("device " + std::to_string(p.device) + ": an evaluation lost an objective partial");
     if (host_out) {
+        DeviceGuard guard;
         std::vector<char> padded(elem() * (size_t)width_ * devices());
         check(hipSetDevice(part_[0].device), "hipSetDevice");
         check(hipMemcpy(padded.data(), part_[0].dAll, padded.size(), hipMemcpyDeviceToHost), "hipMemcpy(gathered)");
@@ -331,6 +343,7 @@ double multi::mean_objective()
     nccl_check(nc.GroupEnd(), "ncclGroupEnd");
     sync();
     double s[2];
+    DeviceGuard guard;
     check(hipSetDevice(part_[0].device), "hipSetDevice");
     check(hipMemcpy(s, part_[0].dSum, sizeof s, hipMemcpyDeviceToHost), "hipMemcpy(sum)");
     return s[1] / (double)total_;
@@ -338,6 +351,7 @@ double multi::mean_objective()
 
 void multi::sync()
 {
+    DeviceGuard guard;
     for (Part &p : part_) {
         check(hipSetDevice(p.device), "hipSetDevice");
         check(hipStreamSynchronize(p.stream), "hipStreamSynchronize");
