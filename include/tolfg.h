@@ -312,6 +312,10 @@ int  tolfg_multi_set_trajectories(tolfg_multi *m, long total, const tolfg_traj *
 int  tolfg_multi_shard(const tolfg_multi *m, int device_index, long *lo, long *hi);
 /* device pointers (on devices[device_index]) of the shard's rows, SNOPT layout, strides in elements of the batch dtype */
 int  tolfg_multi_buffers(const tolfg_multi *m, int device_index, void **dX, long *ldx, void **dF, long *ldf, void **dG, long *ldg);
+/* wind: one gridded field for every device (wind model 3), or -- batches created with TOLFG_WIND_TABLE -- the per-trajectory
+ * tables of ALL trajectories, [total][12][ts+1] doubles in global order (each device receives its shard's rows) */
+int  tolfg_multi_set_wind_grid(tolfg_multi *m, const tolfg_wind_grid *grid);
+int  tolfg_multi_set_wind_tables(tolfg_multi *m, const double *wind_enu);
 /* initial guesses of every trajectory, generated on the devices (ref: InitialCond with each trajectory's start) */
 int  tolfg_multi_x0(tolfg_multi *m);
 /* one evaluation of every shard: one launch per device, asynchronous */

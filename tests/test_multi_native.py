@@ -115,3 +115,45 @@ def test_c_example_runs_on_one_device(tolfg, oracle, tmp_path):
         vals.append(o.eval(o.x0(), needG=False)[0][0])
     assert first == pytest.approx(vals[0], rel=1e-12) and last == pytest.approx(vals[-1], rel=1e-12)
     assert mean == pytest.approx(np.mean(vals), rel=1e-11)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("wind", ["table", "grid"])
+def test_wind_reaches_every_shard(tolfg, oracle, wind):
+    """Per-trajectory wind tables are dealt to the shards in global order; a gridded field goes to every device."""
+    import torch
+    from helpers import random_wind_table
+    from test_wind_grid import make_grid
+    N, B = 64, 11
+    trajs = [tolfg.Trajectory(aircraft=0, radius_goal=100.0, xi=37.0 + 2.0 * t, yi=-41.0 - t, zi=-45.0) for t in range(B)]
+    m = tolfg.Multi("S10", ["tempest"], ts=N, devices=[0], windmodel=tolfg.capi.WIND_TABLE if wind == "table" else tolfg.capi.WIND_SHEAR)
+    m.set_trajectories(trajs)
+    bt = tolfg.Batch("S10", ["tempest"], ts=N, windmodel=tolfg.capi.WIND_TABLE if wind == "table" else tolfg.capi.WIND_SHEAR)
+    bt.set_trajectories(trajs)
+    dW = None
+    if wind == "table":
+        tables = np.stack([random_wind_table(N, 90 + t) for t in range(B)])
+        m.set_wind_tables(tables)
+        dW = torch.from_numpy(tables).cuda()
+    else:
+        g = make_grid(5)
+        m.set_wind_grid(g["v"], g["origin"], g["spacing"], g["datum"])
+        bt.set_wind_grid(g["v"], g["origin"], g["spacing"], g["datum"])
+    m.x0()
+    m.eval()
+    obj = m.gather_objectives()
+    Fm, Gm = m.fetch(0)
+    dX, dF, dG = bt.alloc(B)
+    bt.x0_device(dX)
+    bt.eval(dX, dF, dG, wind=dW)
+    torch.cuda.synchronize()
+    assert np.array_equal(Fm[:, :bt.neF], dF[:, :bt.neF].cpu().numpy()) and np.array_equal(Gm[:, :bt.neG], dG[:, :bt.neG].cpu().numpy())
+    assert np.array_equal(obj, dF[:, 0].cpu().numpy())
+    # the wind really entered: the dt column of the x-defect rows carries -(W_x + Va e_x), different from the shear run
+    ref = tolfg.Batch("S10", ["tempest"], ts=N)
+    ref.set_trajectories(trajs)
+    rF, rG = ref.alloc(B)[1:]
+    ref.eval(dX, rF, rG)
+    torch.cuda.synchronize()
+    assert not torch.equal(rG[:, :ref.neG], dG[:, :bt.neG])
+    m.close()

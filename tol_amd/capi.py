@@ -114,6 +114,8 @@ SYMBOLS = {
     "tolfg_multi_shard": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_long), C.POINTER(C.c_long)]),
     "tolfg_multi_buffers": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_long), C.POINTER(C.c_void_p),
                                       C.POINTER(C.c_long), C.POINTER(C.c_void_p), C.POINTER(C.c_long)]),
+    "tolfg_multi_set_wind_grid": (C.c_int, [C.c_void_p, C.POINTER(WindGrid)]),
+    "tolfg_multi_set_wind_tables": (C.c_int, [C.c_void_p, _dp]),
     "tolfg_multi_x0": (C.c_int, [C.c_void_p]),
     "tolfg_multi_eval": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "tolfg_multi_gather_objectives": (C.c_int, [C.c_void_p, C.c_void_p]),

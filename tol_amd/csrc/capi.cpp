@@ -504,6 +504,18 @@ int tolfg_multi_buffers(const tolfg_multi *h, int i, void **dX, long *ldx, void 
     return TOLFG_OK;
 }
 
+int tolfg_multi_set_wind_grid(tolfg_multi *h, const tolfg_wind_grid *grid)
+{
+    if (!h || !grid) return fail(TOLFG_ERR_ARG, "null argument");
+    return guarded([&] { h->m->set_wind_grid(*grid); });
+}
+
+int tolfg_multi_set_wind_tables(tolfg_multi *h, const double *wind_enu)
+{
+    if (!h || !wind_enu) return fail(TOLFG_ERR_ARG, "null argument");
+    return guarded([&] { h->m->set_wind_tables(wind_enu); });
+}
+
 int tolfg_multi_x0(tolfg_multi *h)
 {
     if (!h) return fail(TOLFG_ERR_ARG, "null handle");

@@ -188,7 +188,7 @@ void multi::free_buffers()
     DeviceGuard guard;
     for (Part &p : part_) {
         (void)hipSetDevice(p.device);
-        for (void **q : {&p.dX, &p.dF, &p.dG, &p.dObj, &p.dAll}) {
+        for (void **q : {&p.dX, &p.dF, &p.dG, &p.dObj, &p.dAll, &p.dWind}) {
             if (*q) (void)hipFree(*q);
             *q = nullptr;
         }
@@ -298,12 +298,39 @@ void multi::x0()
     });
 }
 
+void multi::set_wind_grid(const tolfg_wind_grid &g)
+{
+    sync();
+    on_every_device([&](Part &p) { p.b->set_wind_grid(g); });
+}
+
+void multi::set_wind_tables(const double *wind_enu)
+{
+    if (total_ < 1) throw std::invalid_argument("tolfg_multi: set_trajectories first");
+    if (!wind_enu) throw std::invalid_argument("tolfg_multi_set_wind_tables: null table");
+    sync();
+    const size_t per = 12 * (size_t)(sizes().N + 1);
+    on_every_device([&](Part &p) {
+        const size_t rows = (size_t)(p.hi - p.lo);
+        if (rows == 0) return;
+        check(hipSetDevice(p.device), "hipSetDevice");
+        if (!p.dWind) check(hipMalloc(&p.dWind, elem() * rows * per), "hipMalloc(wind)");
+        const double *src = wind_enu + (size_t)p.lo * per;
+        if (dtype_ == TOLFG_F64) {
+            check(hipMemcpy(p.dWind, src, sizeof(double) * rows * per, hipMemcpyHostToDevice), "hipMemcpy(wind)");
+        } else {
+            std::vector<float> tmp(src, src + rows * per);
+            check(hipMemcpy(p.dWind, tmp.data(), sizeof(float) * rows * per, hipMemcpyHostToDevice), "hipMemcpy(wind)");
+        }
+    });
+}
+
 void multi::eval(bool needF, bool needG)
 {
     if (total_ < 1) throw std::invalid_argument("tolfg_multi: set_trajectories first");
     on_every_device([&](Part &p) {
         if (p.hi > p.lo)
-            p.b->eval((int)(p.hi - p.lo), p.dX, ldx_, p.dF, ldf_, p.dG, ldg_, nullptr, needF ? 1 : 0, needG ? 1 : 0, p.stream,
+            p.b->eval((int)(p.hi - p.lo), p.dX, ldx_, p.dF, ldf_, p.dG, ldg_, p.dWind, needF ? 1 : 0, needG ? 1 : 0, p.stream,
                       needF ? p.dObj : nullptr);
     });
 }

@@ -62,6 +62,10 @@ public:
     void set_trajectories(long total, const tolfg_traj *trajs);
     // device buffers of shard i: rows of the batch dtype in the SNOPT layout, strides in elements
     void buffers(int i, void **dX, long *ldx, void **dF, long *ldf, void **dG, long *ldg) const;
+    // wind for every device: one gridded field (wind model 3), or per-trajectory tables [total][12][ts+1] of doubles in global
+    // order (TOLFG_WIND_TABLE batches; converted to the batch dtype, device i receives its shard's rows)
+    void set_wind_grid(const tolfg_wind_grid &g);
+    void set_wind_tables(const double *wind_enu);
     // initial guesses of every shard, generated on its device
     void x0();
     // one evaluation of every shard: one launch per device, issued concurrently by the per-device host threads
@@ -82,7 +86,7 @@ private:
         long lo = 0, hi = 0;
         std::unique_ptr<batch> b;
         hipStream_t stream = nullptr;
-        void *dX = nullptr, *dF = nullptr, *dG = nullptr, *dObj = nullptr, *dAll = nullptr, *dSum = nullptr;
+        void *dX = nullptr, *dF = nullptr, *dG = nullptr, *dObj = nullptr, *dAll = nullptr, *dSum = nullptr, *dWind = nullptr;
         void *comm = nullptr;
     };
     std::vector<int> dev_;

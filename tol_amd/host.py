@@ -472,6 +472,18 @@ class Multi:
         check(lib().tolfg_multi_shard(self._h, int(i), C.byref(lo), C.byref(hi)))
         return lo.value, hi.value
 
+    def set_wind_grid(self, v, origin, spacing=(150.0, 150.0, 150.0), datum=(0.0, 0.0, 0.0)):
+        g, keep = _wind_grid(v, origin, spacing, datum)
+        check(lib().tolfg_multi_set_wind_grid(self._h, C.byref(g)))
+
+    def set_wind_tables(self, wind_enu):
+        """wind_enu: [total][12][ts+1], the table of every trajectory in global order (batch created with WIND_TABLE)."""
+        w = np.ascontiguousarray(wind_enu, dtype=np.float64)
+        N = (self.n - 1) // 11 - 1
+        if w.shape != (self.total, 12, N + 1):
+            raise capi.TolfgError(capi.ERR_ARG, f"wind tables must be [{self.total}][12][{N + 1}], got {w.shape}")
+        check(lib().tolfg_multi_set_wind_tables(self._h, _d(w)))
+
     def x0(self):
         check(lib().tolfg_multi_x0(self._h))
 
