@@ -36,7 +36,8 @@ static long g_goff = 0;             // goff=: G starts this many elements into i
 static long g_ldg_pad = 0;          // ldgpad=: extra elements between the rows of G (row-stride experiments)
 static int g_stagger = 0;           // stagger=: FgArgs::stagger
 static int g_variant = 0;           // variant=: ablation switches of a -DTOLFG_ABLATE build (256 no arithmetic, 512 no defect stores,
-                                    // 1024 no objective-gradient stores, 2048 no slab stream, 4096 no x window); results are then wrong
+                                    // 1024 no objective-gradient stores, 2048 no slab stream, 4096 no x window: results are then wrong; 8192 = the stream's
+                                    // offset table asked for after the x window instead of before it: results unchanged)
 Shape make_shape(int B, int N, int mission, int dtype)
 {
     Shape s{};
