@@ -15,8 +15,13 @@
  *   (2) the reference's own .param reader, src/parameters.cpp, which does compile from its own file
  *       and is built in place into oracle/_ref/ (oracle/Makefile target `ref`) to check the reader,
  *   (3) an independent central finite-difference check of G against F (tests/test_oracle_fd.py),
- *       which must fail exactly on the reference quirks SURVEY.md Appendix B lists and nowhere else.
- * Everything else about parity with the reference's binary is unpinned.
+ *       which must fail exactly on the reference quirks SURVEY.md Appendix B lists and nowhere else,
+ *   (4) numbers obtained by EXECUTING the text of the reference's own functions -- constructors included since
+ *       round 3 -- with this repository's C-subset interpreter (tools/make_ref_vectors.py, tools/refeval/;
+ *       tests/golden/ref_eval_*.npz; tests/test_ref_eval_*.py): x0, bounds, pattern, F and G for both missions,
+ *       five air-frames, wind models 0 / 1 / 3 / table, shear wind with seeded (Vref, href), ts = 6 ... 2000.
+ *       The executor is this repository's own, so by the build rules this does not count as the compiled reference:
+ *       agreement with the reference's BINARY beyond (1) stays unpinned.
  *
  * All file:line citations are relative to /root/reference/.
  */
