@@ -63,8 +63,9 @@ def main():
     t0 = trace[0]
     md = []
     md.append(f"# rocprofv3 summary `{tag}` -- bench.py, {mission}/ts={ts}/{dtype}, batch {batch} per GPU, 1 MI355X\n")
+    extra = "" if dtype == "f64" and mission == "mixed" else f" --dtype {dtype} --mission {mission} --batch {batch}"
     md.append("Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 50 --warmup 5 "
-              "--no-cpu-baseline --no-configs` (tools/profile_gpu.sh); counters from two further passes of the same "
+              f"--no-cpu-baseline --no-configs{extra}` (tools/profile_gpu.sh); counters from two further passes of the same "
               "command with `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE`.\n")
     md.append("## Kernel time (`--stats`)\n")
     md.append("| kernel | calls | avg us | min us | max us | % |\n|---|---|---|---|---|---|")
@@ -92,7 +93,9 @@ def main():
     md.append(f"- total {(read_bytes+write_bytes)/1e6:.2f} MB = {(read_bytes+write_bytes)/alg:.3f} x algorithmic")
     with open(os.path.join(dst, tag + "_summary.md"), "w") as fh:
         fh.write("\n".join(md) + "\n")
-    with open(os.path.join(dst, "traffic_latest.json"), "w") as fh:
+    # traffic_latest.json is what bench.py replays beside its HEADLINE: written only for the headline's profile
+    tjson = "traffic_latest.json" if os.environ.get("TOLFG_SIDE_PROFILE") != "1" else tag + "_traffic.json"
+    with open(os.path.join(dst, tjson), "w") as fh:
         json.dump({"tag": tag, "batch": batch, "ts": ts, "dtype": dtype, "mission": mission, "pattern": "reference",
                    "source": f"tools/profile_gpu.sh {tag} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
                    "hbm_bytes_per_launch": read_bytes + write_bytes,
