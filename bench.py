@@ -22,12 +22,20 @@ inside the same process group after the headline.  On one GPU also the single-tr
 (device-resident and through the host->host SNOPT callback), the shares one of 8 GPUs gets, and the
 side records (the round-2 headline shape S10/4096, compact pattern, two streams).
 
-Launch: `python bench.py --gpus 1 ...` or, for N > 1,
-`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P
- bench.py --gpus N --steps K --warmup W`.  Rank 0 prints ONE JSON line.
+Launch: `python bench.py --gpus N ...` as a plain command (for N > 1 it starts its own N ranks as a child
+`python -m torch.distributed.run`, before anything touches a GPU, and relays rank 0's line and the exit code) or,
+for N > 1, directly as `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+--master-port P bench.py --gpus N --steps K --warmup W`.  Rank 0 prints ONE JSON line.
+
+Every timed region is preceded by at least --warmup steps AND at least 0.25 s of back-to-back launching (a fresh box
+ramps its clocks over the first milliseconds; `warmup_steps_run` says how many steps that took), and followed by a
+calibration of the box in the same process: the vendor's fill kernel and the bare store loop of the launch's own
+shape (`roofline.box_fill_GBs`, `box_stream_shape_GBs`, `frac_of_box_fill`, `frac_of_box_stream_shape`), so that a
+slow box can be told from a slow kernel.
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -40,6 +48,73 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 AIRCRAFT5 = ("tempest", "skywalker", "tempest_eric", "tempest_wences", "tempest_will")
+MIN_WARM_S = 0.25         # every timed region is preceded by at least this much back-to-back launching (and >= --warmup steps):
+                          # a fresh box is still ramping its clocks during the first milliseconds (profiles/r03_clocks_power.md)
+_BOX = {}                 # per-process calibration of this box (box_fill)
+
+
+def settle(step, fence, warmup, max_over_ranks=None):
+    """Warm-up before a timed region: steps are run back to back, in blocks, until at least `warmup` of them AND at least
+    MIN_WARM_S seconds of launching have gone by.  The block sizes are agreed over the ranks (every rank runs the same
+    number of steps: a step may hold a collective).  Returns the number of steps run."""
+    n, t_start, block = 0, time.perf_counter(), max(int(warmup), 3)
+    while True:
+        t0 = time.perf_counter()
+        for _ in range(block):
+            step(n)
+            n += 1
+        fence()
+        now = time.perf_counter()
+        remaining = MIN_WARM_S - (now - t_start)
+        nxt = 0 if remaining <= 0 else max(1, int(math.ceil(remaining / max((now - t0) / block, 1e-7))))
+        if max_over_ranks is not None:
+            nxt = int(max_over_ranks([float(nxt)])[0])
+        if nxt == 0:
+            return n
+        block = min(nxt, 100000)
+
+
+def box_fill(torch, device):
+    """Calibration, once per process: the vendor's fill kernel (torch.Tensor.fill_, a hipMemset-class kernel) over 800 MB of
+    this GPU's HBM -- what THIS box's write path gives the simplest possible stream (tools/fill_reference.py)."""
+    if "fill_GBs" not in _BOX:
+        n = 100 * 1000 * 1000
+        a = torch.empty(n, dtype=torch.float64, device=device)
+        for _ in range(5):
+            a.fill_(1.5)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(30):
+            a.fill_(2.5)
+        e1.record()
+        torch.cuda.synchronize()
+        _BOX["fill_GBs"] = 8.0 * n * 30 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        del a
+        torch.cuda.empty_cache()
+    return _BOX["fill_GBs"]
+
+
+def store_shape_rate(bt, torch, dXs, dF, dG, B, ts, slab, reps=20):
+    """Calibration: the bare store loop of THIS launch's shape (tolfg_batch_set_store_shape: the evaluation's grid, tile
+    order, resident-wave cap and store flavour with only the Jacobian-slab stores in it), same buffers, same process.
+    Returns (GB/s over the bytes it stores, us per launch).  G holds garbage afterwards (the next evaluation rewrites it)."""
+    bt.set_store_shape(True)
+    try:
+        for _ in range(5):
+            bt.eval(dXs[0], dF, dG, B=B)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            bt.eval(dXs[0], dF, dG, B=B)
+        e1.record()
+        torch.cuda.synchronize()
+    finally:
+        bt.set_store_shape(False)
+    us = 1e3 * e0.elapsed_time(e1) / reps
+    stored = float(dG.element_size()) * B * ts * slab
+    return stored / (us * 1e-6) / 1e9, us
 
 
 def make_trajectories(tol_amd, B, first_index, mission="S10", n_aircraft=1):
@@ -79,9 +154,7 @@ def timed_evals(bt, torch, dXs, dF, dG, B, steps, warmup, obj=None):
     attached to every dispatch (what rocprofv3 --kernel-trace also turns on) -- that costs 10-16 us per launch, part of
     it inside the reported duration (profiles/r02_event_cost.md), so it is reported beside, not as, the figure.
     Returns wall_s, per_launch_ms, instrumented_avg_ms, instrumented_min_ms."""
-    for i in range(warmup):
-        bt.eval(dXs[i % len(dXs)], dF, dG, obj=obj, B=B)
-    torch.cuda.synchronize()
+    settle(lambda i: bt.eval(dXs[i % len(dXs)], dF, dG, obj=obj, B=B), torch.cuda.synchronize, warmup)
     bt.set_timing(False)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
@@ -111,11 +184,15 @@ def device_record(tol_amd, torch, cfg, workload, mission, aircraft, ts, B, dtype
     wall, avg_ms, inst_ms, inst_min_ms = timed_evals(bt, torch, dXs, dF, dG, B, steps, 5, obj)
     assert torch.isfinite(obj).all()
     alg = bt.algorithmic_bytes(B)
+    gbs = alg / (avg_ms * 1e-3) / 1e9
     rec = {"config": cfg, "workload": workload, "mode": "device-resident", "batch": B, "ts": ts, "dtype": dtype, "steps": steps,
            "ms_per_step": 1e3 * wall / steps, "node_evals_per_s": B * ts * steps / wall,
            "eval_us": 1e3 * avg_ms, "eval_us_instrumented": 1e3 * inst_ms, "eval_min_us_instrumented": 1e3 * inst_min_ms, "launches_per_step": 1,
-           "algorithmic_bytes": alg, "achieved_GBs": alg / (avg_ms * 1e-3) / 1e9,
-           "frac_of_hbm_peak": alg / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+           "algorithmic_bytes": alg, "achieved_GBs": gbs,
+           "frac_of_hbm_peak": gbs / HBM_PEAK_GBS, "frac_of_box_fill": gbs / box_fill(torch, dF.device)}
+    if B > 8:       # callback-sized launches take the one-workgroup-per-trajectory kernel: no stream shape to calibrate
+        shape_gbs, shape_us = store_shape_rate(bt, torch, dXs, dF, dG, B, ts, 104)
+        rec.update(box_stream_shape_GBs=shape_gbs, box_stream_shape_us=shape_us, frac_of_box_stream_shape=gbs / shape_gbs)
     bt.close()
     del dXs, dF, dG
     torch.cuda.empty_cache()
@@ -190,6 +267,8 @@ def callback_mode(tol_amd, mission, aircraft, ts, calls, cfg=None):
     assert np.isfinite(F).all() and np.isfinite(G).all() and F[0] != 0.0
     us_f_only, F2, _ = p.time_callback(x, calls, needG=False)      # what snOptA's line search asks for
     assert np.array_equal(F2, F)
+    us_staged, F3, G3 = p.time_callback(x, calls, in_place=False)  # the default contract: every call staged
+    assert np.array_equal(F3, F) and np.array_equal(G3, G)
     p.make_current()
     L = tol_amd.lib()
     dp = C.POINTER(C.c_double)
@@ -209,7 +288,11 @@ def callback_mode(tol_amd, mission, aircraft, ts, calls, cfg=None):
     rec = {"workload": f"{mission}/{aircraft}/ts={ts} single trajectory, DEFINEGusrfg_ host->host (PCIe inclusive)",
            "mode": "callback", "us_per_call": us_native, "node_evals_per_s": 1e6 * ts / us_native, "calls": calls,
            "entered_from": "native code through an snFunA pointer (tolfg_time_callback)",
+           "arrays": "registered in place (tolfg_register_arrays / tolfg_config.persistent_arrays: the kernel reads x and writes "
+                     "F, G in the caller's memory)",
            "us_per_call_needF_only": us_f_only,
+           "us_per_call_staged": us_staged, "node_evals_per_s_staged": 1e6 * ts / us_staged,
+           "arrays_staged": "the default contract: nothing registered, x copied into and F, G out of the library's pinned buffers",
            "us_per_call_via_python_ctypes": 1e6 * dt / calls}
     if cfg is not None:
         rec["config"] = cfg
@@ -234,8 +317,7 @@ def two_streams_record(tol_amd, torch, args, B, device, steps=100):
             for k, (bt, dXs, dF, dG, obj) in enumerate(sets):
                 with torch.cuda.stream(streams[k]):
                     bt.eval(dXs[i % 2], dF, dG, obj=obj)
-    run(5)
-    torch.cuda.synchronize()
+    settle(lambda i: run(1), torch.cuda.synchronize, 5)
     t0 = time.perf_counter()
     run(steps)
     torch.cuda.synchronize()
@@ -247,7 +329,8 @@ def two_streams_record(tol_amd, torch, args, B, device, steps=100):
         s[0].close()
     return {"workload": f"two batches of {B} trajectories in flight on two streams", "evaluations": 2 * steps,
             "us_per_evaluation": 1e6 * wall / (2 * steps), "node_evals_per_s": 2 * steps * B * args.ts / wall,
-            "algorithmic_GBs": alg * 2 * steps / wall / 1e9, "frac_of_hbm_peak": alg * 2 * steps / wall / 1e9 / HBM_PEAK_GBS}
+            "algorithmic_GBs": alg * 2 * steps / wall / 1e9, "frac_of_hbm_peak": alg * 2 * steps / wall / 1e9 / HBM_PEAK_GBS,
+            "frac_of_box_fill": alg * 2 * steps / wall / 1e9 / box_fill(torch, sets[0][2].device)}
 
 
 def single_gpu_records(tol_amd, torch, device):
@@ -292,7 +375,8 @@ class Job:
         return [float(v) for v in t]
 
 
-def sharded_run(tol_amd, job, mission, aircraft, ts, dtype, pattern, per_gpu, global_batch, steps, warmup, x_buffers, instrumented=True):
+def sharded_run(tol_amd, job, mission, aircraft, ts, dtype, pattern, per_gpu, global_batch, steps, warmup, x_buffers, instrumented=True,
+                keep=None):
     """Exactly `steps` steps of one workload over the job's ranks between two barriers.  A step = this rank's shard in ONE
     launch (F, G and the objectives) + the all-gather of the objectives (N > 1; asynchronous, double-buffered, so it
     overlaps the next step's launch).  per_gpu > 0: weak scaling, that many trajectories per rank; else global_batch
@@ -306,9 +390,19 @@ def sharded_run(tol_amd, job, mission, aircraft, ts, dtype, pattern, per_gpu, gl
         lo, hi = shard_bounds(global_batch, rank, world)
         B, first, total, scaling = hi - lo, lo, global_batch, "strong"
         Bmax = shard_bounds(total, 0, world)[1]                     # widest shard (gather buffer)
-    bt = tol_amd.Batch(mission, aircraft, ts=ts, dtype=dtype, device=job.local, pattern=pattern)
-    bt.set_trajectories(make_trajectories(tol_amd, max(B, 1), first, mission, len(aircraft)))
-    dXs, dF, dG = make_inputs(bt, torch, max(B, 1), first, x_buffers)
+    # keep (a dict): the batch object and its buffers outlive this run under the workload's key, and a later run of the
+    # SAME workload on this rank re-uses them -- the speed of a launch depends on where its output buffers landed
+    # (profiles/r04_allocation_classes.md), so two records of one workload are taken on one allocation
+    key = (mission, tuple(aircraft), ts, dtype, pattern, B, first, x_buffers)
+    reused = keep is not None and key in keep
+    if reused:
+        bt, dXs, dF, dG = keep[key]
+    else:
+        bt = tol_amd.Batch(mission, aircraft, ts=ts, dtype=dtype, device=job.local, pattern=pattern)
+        bt.set_trajectories(make_trajectories(tol_amd, max(B, 1), first, mission, len(aircraft)))
+        dXs, dF, dG = make_inputs(bt, torch, max(B, 1), first, x_buffers)
+        if keep is not None:
+            keep[key] = (bt, dXs, dF, dG)
     obj = [torch.zeros(Bmax, dtype=dF.dtype, device=dF.device) for _ in range(2)]
     gdev = dF.device if job.backend == "nccl" else torch.device("cpu")
     allobj = [torch.empty(Bmax * world, dtype=dF.dtype, device=gdev) for _ in range(2)] if world > 1 else None
@@ -331,9 +425,7 @@ def sharded_run(tol_amd, job, mission, aircraft, ts, dtype, pattern, per_gpu, gl
                 pending[s] = None
         job.barrier()
 
-    for i in range(warmup):
-        step(i)
-    fence()
+    warm_run = settle(step, fence, warmup, job.max_over_ranks if world > 1 else None)
     # The timed region: exactly `steps` steps between two barriers.  Two HIP events on the launch stream bracket the
     # launches (before the first, after the last): their distance / steps is the average time per launch, the ~2 us
     # between dependent launches included -- an upper bound of the kernel's own duration, taken without instrumenting it.
@@ -352,7 +444,7 @@ def sharded_run(tol_amd, job, mission, aircraft, ts, dtype, pattern, per_gpu, gl
     if world > 1:      # every rank's shard arrived in place, in global trajectory order
         mine = obj[last].to(allobj[last].device)
         assert torch.equal(allobj[last][rank * Bmax:(rank + 1) * Bmax], mine), "gathered objectives are out of order"
-    out = {"B": B, "total": total, "scaling": scaling, "x_buffers": len(dXs)}
+    out = {"B": B, "total": total, "scaling": scaling, "x_buffers": len(dXs), "buffers_reused": reused}
     # the gather alone (N > 1): synchronous all-gathers of the same buffers, nothing else in flight
     gather_us = 0.0
     if world > 1:
@@ -384,14 +476,22 @@ def sharded_run(tol_amd, job, mission, aircraft, ts, dtype, pattern, per_gpu, gl
         bt.set_timing(False)
     elapsed, kern_ms, gather_us = job.max_over_ranks([elapsed, kern_ms, gather_us])
     out.update(elapsed=elapsed, kern_ms=kern_ms, gather_us=gather_us, inst_ms=inst_ms, inst_min_ms=inst_min_ms, inst_step_ms=inst_step_ms,
-               alg_bytes=bt.algorithmic_bytes(B) if B > 0 else 0.0)
-    bt.close()
+               alg_bytes=bt.algorithmic_bytes(B) if B > 0 else 0.0, warmup_steps_run=warm_run)
+    # Calibration of THIS box in THIS process, right after the timed region (same clocks, same temperature): the vendor's
+    # fill kernel, and the bare store loop of this launch's own shape on the same buffers (rank 0's figures are reported)
+    out["box_fill_GBs"] = box_fill(torch, dF.device)
+    if B > 8:
+        out["box_stream_shape_GBs"], out["box_stream_shape_us"] = store_shape_rate(bt, torch, dXs, dF, dG, B, ts, 46 if pattern == "compact" else 104)
+    job.barrier()
+    if keep is None:
+        bt.close()
     del dXs, dF, dG, obj, allobj
-    torch.cuda.empty_cache()
+    if keep is None:
+        torch.cuda.empty_cache()
     return out
 
 
-def stated_config_records(tol_amd, job, x_buffers):
+def stated_config_records(tol_amd, job, x_buffers, keep=None):
     """configs[3] and configs[4] AS STATED in BASELINE.json -- a global batch of 1024 S10 trajectories, a global mixed
     batch of 8192 in fp64 and fp32 -- sharded over however many GPUs the job has (strong scaling): per step every rank
     evaluates its shard in one launch and the objectives are all-gathered."""
@@ -400,7 +500,7 @@ def stated_config_records(tol_amd, job, x_buffers):
             (3, "configs[3] batch=1024 problemS10 ts=200, randomized wind/IC", "S10", ("tempest",), 1024, "f64", 200),
             (4, "configs[4] mixed G7+S10 batch=8192, five air-frames, ts=200", "mixed", AIRCRAFT5, 8192, "f64", 100),
             (4, "configs[4] mixed G7+S10 batch=8192, five air-frames, ts=200", "mixed", AIRCRAFT5, 8192, "f32", 100)):
-        r = sharded_run(tol_amd, job, mission, aircraft, 200, dtype, "reference", 0, G, steps, 10, x_buffers)
+        r = sharded_run(tol_amd, job, mission, aircraft, 200, dtype, "reference", 0, G, steps, 10, x_buffers, keep=keep)
         if job.rank != 0:
             continue
         world = job.world
@@ -414,9 +514,48 @@ def stated_config_records(tol_amd, job, x_buffers):
                      "algorithmic_bytes": alg_total, "achieved_GBs": alg_total / (r["kern_ms"] * 1e-3) / 1e9,
                      "frac_of_hbm_peak": alg_total / (r["kern_ms"] * 1e-3) / 1e9 / (HBM_PEAK_GBS * world),
                      "frac_of_hbm_peak_whole_step": alg_total / (r["elapsed"] / steps) / 1e9 / (HBM_PEAK_GBS * world),
+                     "warmup_steps_run": r["warmup_steps_run"], "box_fill_GBs": r["box_fill_GBs"],
+                     "buffers": ("the headline's batch object and buffers (the same workload: a second, independent timed region on the "
+                                 "same allocation)" if r["buffers_reused"] else "its own allocation"),
+                     "frac_of_box_fill": alg_total / (r["kern_ms"] * 1e-3) / 1e9 / (r["box_fill_GBs"] * world),
+                     "box_stream_shape_GBs": r.get("box_stream_shape_GBs"), "box_stream_shape_us": r.get("box_stream_shape_us"),
+                     "frac_of_box_stream_shape": (alg_total / (r["kern_ms"] * 1e-3) / 1e9 / (r["box_stream_shape_GBs"] * world)
+                                                  if r.get("box_stream_shape_GBs") else None),
                      "note": "eval_us = slowest rank's time per launch (HIP events on its launch stream); gather_us = one synchronous "
                              "all-gather of the objectives alone; fractions are of n_gpus x 8 TB/s"})
     return recs
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` (N > 1) started as a plain command: start the N ranks as a child
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <the same arguments>`, one rank per GPU,
+    rendezvous on 127.0.0.1 at a free port.  Called before torch is imported or any GPU call is made.  The child's
+    stderr passes through; of its stdout, rank 0's JSON line is printed last, on its own line, and anything else goes
+    to stderr.  Returns the child's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    line = None
+    for ln in child.stdout:
+        if ln.startswith("{") and ln.rstrip().endswith("}"):
+            line = ln.rstrip("\n")
+        else:
+            sys.stderr.write(ln)
+    rc = child.wait()
+    if line is not None:
+        print(line, flush=True)
+    elif rc == 0:
+        sys.stderr.write("bench.py: the ranks ended without a result line\n")
+        rc = 1
+    return rc
 
 
 def main():
@@ -444,6 +583,11 @@ def main():
                          "memory) only rehearses the multi-rank step loop, e.g. several ranks sharing one GPU")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started as a plain command: nothing has touched a GPU yet, so the ranks are started from here as a CHILD
+        # (never an exec) and this process only relays rank 0's line and the child's exit code
+        sys.exit(spawn_ranks(args.gpus))
+
     import torch
     import torch.distributed as dist
     import tol_amd
@@ -452,8 +596,6 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     ndev = torch.cuda.device_count()
@@ -485,11 +627,16 @@ def main():
     job = Job(torch, dist, world, rank, local, args.backend)
 
     aircraft = AIRCRAFT5 if args.mission == "mixed" else (args.aircraft,)
+    keep = {}        # the headline's batch and buffers: re-used by a stated config of the same workload (one GPU: configs[4] fp64)
     r = sharded_run(tol_amd, job, args.mission, aircraft, args.ts, args.dtype, args.pattern,
-                    0 if args.global_batch > 0 else args.batch, args.global_batch, args.steps, args.warmup, args.x_buffers)
+                    0 if args.global_batch > 0 else args.batch, args.global_batch, args.steps, args.warmup, args.x_buffers, keep=keep)
     configs = None
     if not args.no_configs:
-        configs = stated_config_records(tol_amd, job, args.x_buffers)      # every rank takes part
+        configs = stated_config_records(tol_amd, job, args.x_buffers, keep=keep)      # every rank takes part
+    for held in keep.values():
+        held[0].close()
+    keep.clear()
+    torch.cuda.empty_cache()
 
     if rank == 0:
         B, total = r["B"], r["total"]
@@ -517,6 +664,7 @@ def main():
         line = {
             "metric": "collocation-node F/G+Jacobian evals/sec",
             "value": value, "unit": "node-evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "warmup_steps_run": r["warmup_steps_run"],
             "ms_per_step": 1e3 * r["elapsed"] / args.steps, "higher_is_better": True, "scaling": r["scaling"],
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic", "backend": backend,
             "config": {"workload": what + f": a device-resident batch of {B} trajectories per GPU with randomized shear wind and "
@@ -526,6 +674,13 @@ def main():
                        "parallelism": (f"batch-sharded x{world}, {backend} all-gather of objectives") if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                         "box_fill_GBs": r["box_fill_GBs"], "frac_of_box_fill": achieved / r["box_fill_GBs"],
+                         "box_stream_shape_GBs": r.get("box_stream_shape_GBs"), "box_stream_shape_us": r.get("box_stream_shape_us"),
+                         "frac_of_box_stream_shape": achieved / r["box_stream_shape_GBs"] if r.get("box_stream_shape_GBs") else None,
+                         "calibration": "measured in this process on this box right after the timed region: box_fill = the vendor's fill "
+                                        "kernel (torch fill_) over 800 MB; box_stream_shape = this launch's own grid, tile order, "
+                                        "resident-wave cap and store flavour with nothing in it but the Jacobian-slab stores "
+                                        "(tolfg_batch_set_store_shape), GB/s over the bytes it stores; frac_of_* = achieved / that",
                          "kernel": "tolfg::fg_kernel (the whole evaluation: the last tile wave of a trajectory finalizes it)",
                          "kernel_ms": r["kern_ms"],
                          "timing": "kernel_ms = (HIP event after the last launch - HIP event before the first) / steps, on the launch "
@@ -572,9 +727,13 @@ def compact_side_run(tol_amd, torch, args, B, device, steps=50):
     obj = torch.empty(B, dtype=dF.dtype, device=dF.device)
     wall, kms, _, _ = timed_evals(bc, torch, dXs, dF, dG, B, steps, 5, obj)
     alg = bc.algorithmic_bytes(B)
+    gbs = alg / (kms * 1e-3) / 1e9
+    shape_gbs, shape_us = store_shape_rate(bc, torch, dXs, dF, dG, B, args.ts, 46)
     return {"value": B * args.ts * steps / wall, "unit": "node-evals/s", "steps": steps, "ms_per_step": 1e3 * wall / steps,
-            "kernel_ms": kms, "algorithmic_bytes_per_launch": alg, "achieved_GBs": alg / (kms * 1e-3) / 1e9,
-            "frac_of_hbm_peak": alg / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, "bytes_per_node": alg / (B * args.ts)}
+            "kernel_ms": kms, "algorithmic_bytes_per_launch": alg, "achieved_GBs": gbs,
+            "frac_of_hbm_peak": gbs / HBM_PEAK_GBS, "bytes_per_node": alg / (B * args.ts),
+            "frac_of_box_fill": gbs / box_fill(torch, dF.device), "box_stream_shape_GBs": shape_gbs, "box_stream_shape_us": shape_us,
+            "frac_of_box_stream_shape": gbs / shape_gbs}
 
 
 if __name__ == "__main__":

@@ -188,6 +188,11 @@ int tolfg_registered_arrays(const tolfg_problem *p);
  * or a negative TOLFG_ERR_*. */
 int tolfg_time_callback(tolfg_problem *p, const double *x, double *F, double *G, int needF, int needG, int warm, int calls,
                         double *us_per_call);
+/* The same with the array contract named: in_place = 1 is tolfg_time_callback (arrays registered for the duration);
+ * in_place = 0 times the DEFAULT contract -- nothing registered, every call copies x into and F, G out of the library's
+ * pinned staging buffers. */
+int tolfg_time_callback_as(tolfg_problem *p, const double *x, double *F, double *G, int needF, int needG, int in_place, int warm,
+                           int calls, double *us_per_call);
 
 /* The three public methods DEFINEGusrfg_ dispatches to in the reference
  * (ref: problem::modelWind / computeF / computeG, src/problem.cpp:475,765,782), for callers that
@@ -288,6 +293,13 @@ int  tolfg_batch_objectives(tolfg_batch *b, int B, const void *dF, long ldf, voi
  * launch takes 4-16 us longer while it is on (profiles/r02_event_cost.md), so bench.py keeps it out of its timed region. */
 int  tolfg_batch_set_timing(tolfg_batch *b, int enable);
 int  tolfg_batch_kernel_time(tolfg_batch *b, double *avg_ms, double *min_ms);
+/* Measurement aid (calibration of a box).  While enabled, tolfg_batch_eval launches -- instead of the evaluation -- a
+ * bare store loop in the evaluation's own launch shape: the same grid (one wave per tile), tile order over the XCDs,
+ * resident-wave cap and store flavour (non-temporal or plain), every wave writing the 16-byte vectors of its tile's
+ * Jacobian slab region with a constant; no loads, no arithmetic.  Its rate is what the write path of THIS box gives
+ * THIS stream shape; bench.py measures it in the same process as the evaluation (roofline.box_stream_shape_GBs).
+ * F and G hold garbage while it is on. */
+int  tolfg_batch_set_store_shape(tolfg_batch *b, int enable);
 
 /* algorithmic bytes one evaluation of trajectories [0,B) moves: elemsize * sum of (n + neF + neG)
  * (SURVEY.md section 8d), with each trajectory's own mission sizes and the batch's pattern */

@@ -85,6 +85,7 @@ SYMBOLS = {
     "tolfg_forget_arrays": (C.c_int, [C.c_void_p]),
     "tolfg_registered_arrays": (C.c_int, [C.c_void_p]),
     "tolfg_time_callback": (C.c_int, [C.c_void_p, _dp, _dp, _dp, C.c_int, C.c_int, C.c_int, C.c_int, _dp]),
+    "tolfg_time_callback_as": (C.c_int, [C.c_void_p, _dp, _dp, _dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _dp]),
     "tolfg_modelWind": (C.c_int, [C.c_void_p, _dp]),
     "tolfg_computeF": (C.c_int, [C.c_void_p, _dp, _dp]),
     "tolfg_computeG": (C.c_int, [C.c_void_p, _dp, _dp]),
@@ -106,6 +107,7 @@ SYMBOLS = {
     "tolfg_batch_objectives": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_long, C.c_void_p, C.c_void_p]),
     "tolfg_batch_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "tolfg_batch_kernel_time": (C.c_int, [C.c_void_p, _dp, _dp]),
+    "tolfg_batch_set_store_shape": (C.c_int, [C.c_void_p, C.c_int]),
     "tolfg_batch_algorithmic_bytes": (C.c_double, [C.c_void_p, C.c_int]),
     "tolfg_multi_create": (C.c_int, [C.POINTER(BatchConfig), _ip, C.c_int, C.POINTER(C.c_void_p)]),
     "tolfg_multi_destroy": (None, [C.c_void_p]),

@@ -247,6 +247,12 @@ int tolfg_registered_arrays(const tolfg_problem *h)
 int tolfg_time_callback(tolfg_problem *h, const double *x, double *F, double *G, int needF, int needG, int warm, int calls,
                         double *us_per_call)
 {
+    return tolfg_time_callback_as(h, x, F, G, needF, needG, 1, warm, calls, us_per_call);
+}
+
+int tolfg_time_callback_as(tolfg_problem *h, const double *x, double *F, double *G, int needF, int needG, int in_place, int warm,
+                           int calls, double *us_per_call)
+{
     if (!h || !x || !F || !G || calls < 1 || !us_per_call) return fail(TOLFG_ERR_ARG, "tolfg_time_callback: bad argument");
     typedef void (*snFunA)(int *, int *, double *, int *, int *, double *, int *, int *, double *, char *, int *, int *, int *,
                            double *, int *);     // ref: include/snopt/snopt.h:60-66
@@ -259,7 +265,10 @@ int tolfg_time_callback(tolfg_problem *h, const double *x, double *F, double *G,
     // aligned) and forgotten before it returns, so nothing stays pinned that the caller may free
     double *xs = const_cast<double *>(x);          // snFunA takes double x[]; the callback only reads it
     auto al = [](const void *p) { return reinterpret_cast<uintptr_t>(p) % 16 == 0; };
-    const int rc = guarded([&] { h->p->register_arrays(al(xs) ? xs : nullptr, al(F) ? F : nullptr, al(G) ? G : nullptr); });
+    // in_place = 0: the default contract -- nothing is registered, every call copies x into and F, G out of the library's
+    // pinned staging buffers
+    const int rc = in_place ? guarded([&] { h->p->register_arrays(al(xs) ? xs : nullptr, al(F) ? F : nullptr, al(G) ? G : nullptr); })
+                            : guarded([&] { h->p->forget_arrays(); });
     if (rc != TOLFG_OK) { tolfg_set_current(keep); return rc; }
     for (int i = 0; i < warm; ++i) usrfun(&Status, &n, xs, &wantF, &neF, F, &wantG, &neG, G, nullptr, &zero, nullptr, &zero, nullptr, &zero);
     const auto t0 = std::chrono::steady_clock::now();
@@ -431,6 +440,12 @@ int tolfg_batch_set_timing(tolfg_batch *h, int enable)
 {
     if (!h) return fail(TOLFG_ERR_ARG, "null batch");
     return guarded([&] { h->b->set_timing(enable != 0); });
+}
+
+int tolfg_batch_set_store_shape(tolfg_batch *h, int enable)
+{
+    if (!h) return fail(TOLFG_ERR_ARG, "null batch");
+    return guarded([&] { h->b->set_store_shape(enable != 0); });
 }
 
 int tolfg_batch_kernel_time(tolfg_batch *h, double *avg_ms, double *min_ms)

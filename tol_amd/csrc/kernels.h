@@ -74,6 +74,8 @@ struct FgArgs {
                            // 0 = finalize_kernel follows fg_kernel
     int  stagger;          // 1 = waves take an issue priority from their slot on the SIMD (launches whose waves all start together)
     int  nt_stores;        // 1 = the slab stream carries the non-temporal hint (outputs beyond the Infinity Cache)
+    int  store_shape;      // measurement aid: 1 = launch store_shape_kernel (this launch's grid, tile order, LDS request and
+                           // store flavour around nothing but the slab stores) instead of the evaluation
     int  xcd_chunk;        // workgroup id < 8 * xcd_chunk -> tile (id % 8) * xcd_chunk + id / 8 (every XCD walks a contiguous
                            // run of xcd_chunk tiles); id >= 8 * xcd_chunk -> tile id.  0 <= xcd_chunk <= ceil(B*tiles/8)
     double *partial;       // [B*tiles][2] objective partials (sum T^2, sum (r-R)^2), device; on the fused path

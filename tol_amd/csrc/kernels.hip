@@ -1056,6 +1056,34 @@ __global__ __launch_bounds__(TILE, TOLFG_MIN_WAVES_PER_SIMD) void fg_kernel(cons
     if (a.done) signal_done(a, (int)total_tiles(a), lane == 0);
 }
 
+// Measurement aid (FgArgs::store_shape, tolfg_batch_set_store_shape): fg_kernel's launch -- the same grid, tile order,
+// LDS request (resident-wave cap) and store flavour -- with nothing in it but the slab stream's stores: every wave
+// writes the whole 16-byte vectors of its tile's slab region with a constant.  No loads, no arithmetic, no LDS
+// traffic: what the write path gives THIS stream shape on THIS box, measured in the same process as the evaluation
+// (bench.py: roofline.box_stream_shape_GBs).  G holds garbage afterwards.
+template <typename T, int PAT, bool NT>
+__global__ __launch_bounds__(TILE) void store_shape_kernel(const FgArgs a, int mission)
+{
+    typedef StreamGeom<(int)sizeof(T), PAT> Gm;
+    typedef typename Vec<T, Gm::GV>::type vec;
+    const int lane = threadIdx.x;
+    int item = blockIdx.x;
+    if (item < 8 * a.xcd_chunk) item = (item & 7) * a.xcd_chunk + (item >> 3);
+    if (item >= total_tiles(a)) return;
+    const TileAt at = tile_at(a, item);
+    const int cnt = min(at.nt, a.N - at.k0);
+    const int ms = mission == MISSION_MIXED ? __builtin_amdgcn_readfirstlane(a.traj[at.b].mission) : mission;
+    T *g = static_cast<T *>(a.G) + (long)at.b * a.ldg + a.c0[ms] + (long)Gm::SLABN * at.k0;
+    const int shift = (int)((reinterpret_cast<unsigned long long>(g) / sizeof(T)) % Gm::GV);
+    const int qhi = (Gm::SLABN * cnt + shift) / Gm::GV;
+    vec *gp = reinterpret_cast<vec *>(g - shift);
+    vec v;
+#pragma unroll
+    for (int i = 0; i < Gm::GV; i++) v[i] = T(1 + lane);
+    for (int q = lane + (shift ? TILE : 0); q < qhi; q += TILE) stream_store<NT>(gp + q, v);
+    if (shift && lane > 0 && lane < qhi) stream_store<NT>(gp + lane, v);
+}
+
 template <typename T, int MISSION, int PAT>
 __global__ __launch_bounds__(TILE) void finalize_kernel(const FgArgs a)
 {
@@ -1161,6 +1189,11 @@ hipError_t launch_vec(const FgArgs &a, int vec, dim3 grid, hipStream_t s, hipEve
         if (st || en) hipExtLaunchKernelGGL(kernel, g, dim3(TILE), ldsz, s, st, en, 0, a);
         else hipLaunchKernelGGL(kernel, g, dim3(TILE), ldsz, s, a);
     };
+    if (a.store_shape) {              // measurement aid: the launch's shape with only the slab stores in it
+        if (a.nt_stores) hipLaunchKernelGGL((store_shape_kernel<T, PAT, true>), grid, dim3(TILE), lds, s, a, (int)MISSION);
+        else             hipLaunchKernelGGL((store_shape_kernel<T, PAT, false>), grid, dim3(TILE), lds, s, a, (int)MISSION);
+        return hipGetLastError();
+    }
     if (vec == VMAX) {
         if (a.nt_stores) go(fg_kernel<T, MISSION, WIND, VMAX, PAT, true, NP>, grid, lds, t0, fg_end);
         else             go(fg_kernel<T, MISSION, WIND, VMAX, PAT, false, NP>, grid, lds, t0, fg_end);

@@ -82,19 +82,29 @@ const rccl_api &rccl_api::get()
     static std::string failure;
     std::call_once(once, [] {
         std::vector<std::string> names;
-        if (const char *e = std::getenv("TOLFG_RCCL_LIBRARY")) names.emplace_back(e);
         const std::string dir = hip_runtime_dir();
-        if (!dir.empty()) { names.push_back(dir + "librccl.so.1"); names.push_back(dir + "librccl.so"); }
-        names.emplace_back("librccl.so.1");
-        names.emplace_back("librccl.so");
-        // a copy the process already holds wins (PyTorch maps its own); otherwise the one beside the HIP runtime
-        for (int pass = 0; pass < 2 && !api.handle; ++pass)
-            for (const std::string &n : names) {
-                api.handle = dlopen(n.c_str(), RTLD_NOW | RTLD_GLOBAL | (pass == 0 ? RTLD_NOLOAD : 0));
-                if (api.handle) { api.path = n; break; }
+        if (const char *e = std::getenv("TOLFG_RCCL_LIBRARY")) {
+            // an explicit choice is final: that library or a failure, never a silent second pick
+            api.handle = dlopen(e, RTLD_NOW | RTLD_GLOBAL);
+            if (!api.handle) {
+                const char *why = dlerror();
+                failure = std::string("TOLFG_RCCL_LIBRARY=") + e + " cannot be loaded: " + (why ? why : "?");
+                return;
             }
+            api.path = e;
+        } else {
+            if (!dir.empty()) { names.push_back(dir + "librccl.so.1"); names.push_back(dir + "librccl.so"); }
+            names.emplace_back("librccl.so.1");
+            names.emplace_back("librccl.so");
+            // a copy the process already holds wins (PyTorch maps its own); otherwise the one beside the HIP runtime
+            for (int pass = 0; pass < 2 && !api.handle; ++pass)
+                for (const std::string &n : names) {
+                    api.handle = dlopen(n.c_str(), RTLD_NOW | RTLD_GLOBAL | (pass == 0 ? RTLD_NOLOAD : 0));
+                    if (api.handle) { api.path = n; break; }
+                }
+        }
         if (!api.handle) {
-            failure = "librccl was not found (tried TOLFG_RCCL_LIBRARY, the HIP runtime's directory '" + dir + "', the default search path)";
+            failure = "librccl was not found (tried the HIP runtime's directory '" + dir + "' and the default search path; TOLFG_RCCL_LIBRARY names one explicitly)";
             return;
         }
         auto sym = [&](const char *name) {
@@ -120,9 +130,15 @@ multi::multi(const std::string &mission, const std::string &root, const std::vec
     : dev_(devices), dtype_(dtype)
 {
     if (devices.empty() || devices.size() > 64) throw std::invalid_argument("tolfg_multi: 1..64 devices");
-    for (size_t i = 0; i < devices.size(); ++i)
-        for (size_t j = 0; j < i; ++j)
-            if (devices[i] == devices[j]) throw std::invalid_argument("tolfg_multi: every device may appear once");
+    // Test seam: TOLFG_MULTI_SHARED_DEVICES=1 lets an ordinal appear more than once, so that several parts -- their
+    // issuing threads, shard dealing, per-shard uploads and the padded gather -- run on a box with ONE GPU.  RCCL itself
+    // refuses duplicate devices in ncclCommInitAll, so this only works with a stand-in collective library named by
+    // TOLFG_RCCL_LIBRARY (tests/loopback_nccl).  Never set in production.
+    const char *shared = std::getenv("TOLFG_MULTI_SHARED_DEVICES");
+    if (!(shared && shared[0] == '1'))
+        for (size_t i = 0; i < devices.size(); ++i)
+            for (size_t j = 0; j < i; ++j)
+                if (devices[i] == devices[j]) throw std::invalid_argument("tolfg_multi: every device may appear once");
     part_.resize(devices.size());
     for (size_t i = 0; i < devices.size(); ++i) {
         Part &p = part_[i];
@@ -186,6 +202,8 @@ void multi::release()
 void multi::free_buffers()
 {
     DeviceGuard guard;
+    if (hAll_) (void)hipHostFree(hAll_);
+    hAll_ = nullptr;
     for (Part &p : part_) {
         (void)hipSetDevice(p.device);
         for (void **q : {&p.dX, &p.dF, &p.dG, &p.dObj, &p.dAll, &p.dWind}) {
@@ -264,6 +282,11 @@ void multi::set_trajectories(long total, const tolfg_traj *trajs)
     width_ = shard_width(total, world);
     ldx_ = up(sz.n); ldf_ = up(sz.neF); ldg_ = up(sz.neG);
     for (int i = 0; i < world; ++i) shard_bounds(total, i, world, &part_[i].lo, &part_[i].hi);
+    {
+        DeviceGuard guard;
+        check(hipSetDevice(part_[0].device), "hipSetDevice");
+        check(hipHostMalloc(&hAll_, elem() * (size_t)width_ * world, hipHostMallocDefault), "hipHostMalloc(gathered)");
+    }
     on_every_device([&](Part &p) {
         check(hipSetDevice(p.device), "hipSetDevice");
         const long B = p.hi - p.lo;
@@ -345,16 +368,16 @@ void multi::gather_objectives(void *host_out)
         nccl_check(nc.AllGather(p.dObj, p.dAll, (size_t)width_, dtype_ == TOLFG_F64 ? kNcclFloat64 : kNcclFloat32, p.comm, p.stream),
                    "ncclAllGather");
     nccl_check(nc.GroupEnd(), "ncclGroupEnd");
+    if (host_out) {      // device 0's copy of the gathered vector follows its gather on the same stream, into pinned memory
+        DeviceGuard guard;
+        check(hipSetDevice(part_[0].device), "hipSetDevice");
+        check(hipMemcpyAsync(hAll_, part_[0].dAll, elem() * (size_t)width_ * devices(), hipMemcpyDeviceToHost, part_[0].stream),
+              "hipMemcpyAsync(gathered)");
+    }
     sync();
     for (Part &p : part_)
         if (p.b->take_lost_partial()) throw hip_failure("device " + std::to_string(p.device) + ": an evaluation lost an objective partial");
-    if (host_out) {
-        DeviceGuard guard;
-        std::vector<char> padded(elem() * (size_t)width_ * devices());
-        check(hipSetDevice(part_[0].device), "hipSetDevice");
-        check(hipMemcpy(padded.data(), part_[0].dAll, padded.size(), hipMemcpyDeviceToHost), "hipMemcpy(gathered)");
-        compact_gathered(padded.data(), elem(), total_, devices(), host_out);
-    }
+    if (host_out) compact_gathered(hAll_, elem(), total_, devices(), host_out);
 }
 
 double multi::mean_objective()

@@ -46,7 +46,8 @@ struct rccl_api {
 
 class multi {
 public:
-    // devices: HIP device ordinals, all different.  Communicators are created here (ncclCommInitAll).
+    // devices: HIP device ordinals, all different (TOLFG_MULTI_SHARED_DEVICES=1, a test seam, lifts that: multi.cpp).
+    // Communicators are created here (ncclCommInitAll).
     multi(const std::string &mission, const std::string &root, const std::vector<std::string> &aircraft_names, int ts,
           int windmodel, int dtype, int pattern, const std::vector<int> &devices);
     ~multi();
@@ -93,6 +94,7 @@ private:
     std::vector<Part> part_;
     int dtype_;
     long total_ = 0, width_ = 0, ldx_ = 0, ldf_ = 0, ldg_ = 0;
+    void *hAll_ = nullptr;            // pinned host copy of the gathered, padded objectives (gather_objectives with host_out)
     size_t elem() const { return dtype_ == TOLFG_F64 ? 8 : 4; }
     void free_buffers();
     void release();

@@ -364,9 +364,10 @@ void batch::eval(int B, const void *dX, long ldx, void *dF, long ldf, void *dG, 
     a.X = dX; a.ldx = ldx; a.F = dF; a.ldf = ldf; a.G = dG; a.ldg = ldg;
     a.wind = dWind; a.traj = d_traj_;
     a.B = B; a.needF = needF ? 1 : 0; a.needG = needG ? 1 : 0;
+    a.store_shape = (store_shape_ && !a.single && needG) ? 1 : 0;
     const int vec = aligned ? vmax : 1;
     hipEvent_t t0 = nullptr, t1 = nullptr;
-    if (timing_) {                 // HIP events on the launch stream, around the whole evaluation
+    if (timing_ && !a.store_shape) {   // HIP events on the launch stream, around the whole evaluation
         if (ev_used_ + 2 > ev_.size()) {
             const size_t old = ev_.size();
             ev_.resize(old + 64, nullptr);

@@ -77,6 +77,8 @@ public:
     // measurement aid: HIP events recorded on the launch stream around fg_kernel of every eval
     void set_timing(bool on);
     int kernel_time(double *avg_ms, double *min_ms);   // launches averaged since the last call
+    // measurement aid: while on, eval() launches the bare store loop of its own launch shape (store_shape_kernel)
+    void set_store_shape(bool on) { store_shape_ = on; }
 
 private:
     Sizes sz_;
@@ -92,6 +94,7 @@ private:
     int waves_per_cu_ = 0;              // TOLFG_WAVES_PER_CU (measurements)
     bool waves_forced_ = false;
     bool timing_ = false;
+    bool store_shape_ = false;
     std::vector<hipEvent_t> ev_;
     size_t ev_used_ = 0;
     void *d_grid_ = nullptr;

@@ -164,13 +164,16 @@ class Problem:
                                 C.byref(neG), _d(G), None, C.byref(zero), None, C.byref(zero), None, C.byref(zero))
         return F, G, st.value
 
-    def time_callback(self, x, calls, warm=50, needF=True, needG=True):
+    def time_callback(self, x, calls, warm=50, needF=True, needG=True, in_place=True):
         """Mean wall time (us) of one DEFINEGusrfg_ call entered from native code like snOptA enters it; F and G
-        are the same arrays every call.  Returns (us_per_call, F, G)."""
+        are the same arrays every call.  in_place: the arrays are registered for the duration (the contract a SNOPT driver
+        enters with tolfg_register_arrays / persistent_arrays); False times the default contract, every call staged
+        through the library's pinned buffers.  Returns (us_per_call, F, G)."""
         x = np.ascontiguousarray(x, dtype=np.float64)
         F, G = np.zeros(self.neF), np.zeros(self.neG)
         us = C.c_double()
-        st = lib().tolfg_time_callback(self._h, _d(x), _d(F), _d(G), int(needF), int(needG), int(warm), int(calls), C.byref(us))
+        st = lib().tolfg_time_callback_as(self._h, _d(x), _d(F), _d(G), int(needF), int(needG), int(bool(in_place)), int(warm), int(calls),
+                                          C.byref(us))
         if st != 1:
             check(st if st < 0 else capi.ERR_HIP)
         return us.value, F, G
@@ -404,6 +407,10 @@ class Batch:
     def set_timing(self, on=True):
         check(lib().tolfg_batch_set_timing(self._h, int(bool(on))))
 
+    def set_store_shape(self, on=True):
+        """Measurement aid: while on, eval() launches the bare store loop of its own launch shape (F, G: garbage)."""
+        check(lib().tolfg_batch_set_store_shape(self._h, int(bool(on))))
+
     def kernel_time(self):
         """(launches, avg_ms, min_ms) of fg_kernel since the last call (HIP events on the launch stream)."""
         a, m = C.c_double(), C.c_double()
@@ -503,8 +510,9 @@ class Multi:
     def sync(self):
         check(lib().tolfg_multi_sync(self._h))
 
-    def fetch(self, i):
-        """(F, G) of shard i as host arrays [rows][ld] (device-to-host copies with the HIP runtime the library uses)."""
+    def fetch(self, i, with_x=False):
+        """(F, G) -- with_x: (X, F, G) -- of shard i as host arrays [rows][ld] (device-to-host copies with the HIP runtime
+        the library uses)."""
         dX, dF, dG = C.c_void_p(), C.c_void_p(), C.c_void_p()
         ldx, ldf, ldg = C.c_long(), C.c_long(), C.c_long()
         check(lib().tolfg_multi_buffers(self._h, int(i), C.byref(dX), C.byref(ldx), C.byref(dF), C.byref(ldf), C.byref(dG), C.byref(ldg)))
@@ -515,10 +523,10 @@ class Multi:
         hip = capi._hip_runtime
         hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
         hip.hipSetDevice(self.devices[i])
-        for ptr, ld in ((dF, ldf.value), (dG, ldg.value)):
+        for ptr, ld in ((dX, ldx.value),) * bool(with_x) + ((dF, ldf.value), (dG, ldg.value)):
             a = np.zeros((hi - lo, ld), dtype=dt)
             rc = hip.hipMemcpy(a.ctypes.data, ptr, a.nbytes, 2)       # hipMemcpyDeviceToHost
             if rc != 0:
                 raise capi.TolfgError(capi.ERR_HIP, f"hipMemcpy failed with {rc}")
             out.append(a)
-        return out[0], out[1]
+        return tuple(out)
