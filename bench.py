@@ -50,6 +50,7 @@ HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MI
 AIRCRAFT5 = ("tempest", "skywalker", "tempest_eric", "tempest_wences", "tempest_will")
 MIN_WARM_S = 0.25         # every timed region is preceded by at least this much back-to-back launching (and >= --warmup steps):
                           # a fresh box is still ramping its clocks during the first milliseconds (profiles/r03_clocks_power.md)
+CALIBRATE = True          # --no-calibration: the calibration launches are skipped (NaN in their fields)
 _BOX = {}                 # per-process calibration of this box (box_fill)
 
 
@@ -77,6 +78,8 @@ def settle(step, fence, warmup, max_over_ranks=None):
 def box_fill(torch, device):
     """Calibration, once per process: the vendor's fill kernel (torch.Tensor.fill_, a hipMemset-class kernel) over 800 MB of
     this GPU's HBM -- what THIS box's write path gives the simplest possible stream (tools/fill_reference.py)."""
+    if not CALIBRATE:
+        return float("nan")
     if "fill_GBs" not in _BOX:
         n = 100 * 1000 * 1000
         a = torch.empty(n, dtype=torch.float64, device=device)
@@ -99,6 +102,8 @@ def store_shape_rate(bt, torch, dXs, dF, dG, B, ts, slab, reps=20):
     """Calibration: the bare store loop of THIS launch's shape (tolfg_batch_set_store_shape: the evaluation's grid, tile
     order, resident-wave cap and store flavour with only the Jacobian-slab stores in it), same buffers, same process.
     Returns (GB/s over the bytes it stores, us per launch).  G holds garbage afterwards (the next evaluation rewrites it)."""
+    if not CALIBRATE:
+        return float("nan"), float("nan")
     bt.set_store_shape(True)
     try:
         for _ in range(5):
@@ -559,6 +564,7 @@ def spawn_ranks(n):
 
 
 def main():
+    global MIN_WARM_S, CALIBRATE
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=500)
@@ -578,11 +584,16 @@ def main():
                          "Cache, so every step reads its X from HBM rather than from a cache that kept it")
     ap.add_argument("--pattern", default="reference", choices=["reference", "compact"],
                     help="Jacobian sparsity pattern; the headline metric is quoted on the reference's own pattern")
+    ap.add_argument("--min-warm-seconds", type=float, default=MIN_WARM_S,
+                    help="every timed region is preceded by at least this much back-to-back launching (and >= --warmup steps)")
+    ap.add_argument("--no-calibration", action="store_true",
+                    help="skip the same-process box calibration (vendor fill, bare store loop); for profiler passes")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N > 1: nccl = RCCL over xGMI; gloo (objectives staged through host "
                          "memory) only rehearses the multi-rank step loop, e.g. several ranks sharing one GPU")
     args = ap.parse_args()
 
+    MIN_WARM_S, CALIBRATE = max(args.min_warm_seconds, 0.0), not args.no_calibration
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # started as a plain command: nothing has touched a GPU yet, so the ranks are started from here as a CHILD
         # (never an exec) and this process only relays rank 0's line and the child's exit code

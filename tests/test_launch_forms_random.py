@@ -55,3 +55,43 @@ def test_single_launch_equals_two_launch_on_random_shapes(tolfg, monkeypatch, se
         what = (mission, N, B, dtype, pattern)
         assert same(outs[0][1], outs[1][1]), what
         assert same(outs[0][0], outs[1][0]), what
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_rows_through_lds_in_two_passes_equal_one_pass(tolfg, monkeypatch, seed):
+    """FgArgs::sub_nodes = 32 (a tile's Jacobian rows go through LDS 32 nodes at a time, TOLFG_SUB_NODES) against the
+    whole-tile form: bitwise the same F and G, for slab regions on and off 16-byte boundaries (odd ts; G7 rows in fp32), both
+    patterns, tiles of 33..64 nodes, short last tiles, and a G buffer that itself sits off a boundary."""
+    import torch
+    rng = np.random.default_rng(4400 + seed)
+    for case in range(7):
+        mission = ("S10", "G7", "mixed")[int(rng.integers(3))]
+        N = int(rng.choice([33, 34, 52, 53, 63, 64, 65, 97, 100, 128, 199, 200, 257]))
+        B = int(rng.choice([1, 3, 10, 33, 127, 700]))
+        dtype = ("f64", "f32")[int(rng.integers(2))]
+        pattern = ("reference", "compact")[int(rng.integers(2))]
+        off = int(rng.integers(0, 4))
+        trajs = [tolfg.Trajectory(aircraft=t % 5, mission=("S10", "G7")[t % 2] if mission == "mixed" else mission,
+                                  radius_goal=100.0 if (mission == "S10" or (mission == "mixed" and t % 2 == 0)) else 0.0,
+                                  Vref=1.0 + 0.01 * (t % 97), xi=float(t % 7), zi=-30.0 - (t % 11)) for t in range(B)]
+        outs = []
+        for sub in ("0", "32"):
+            monkeypatch.setenv("TOLFG_SUB_NODES", sub)
+            monkeypatch.setenv("TOLFG_NO_SINGLE_LAUNCH", "1")
+            bt = tolfg.Batch(mission, AIRCRAFT, ts=N, dtype=dtype, pattern=pattern)
+            bt.set_trajectories(trajs)
+            dX, dF, dGfull = bt.alloc(B)
+            ld = dGfull.shape[1]
+            flat = torch.full((B * ld + 8,), float("nan"), dtype=dGfull.dtype, device="cuda")
+            dG = flat[off:off + B * ld].view(B, ld)                  # G off a 16-byte boundary by `off` elements
+            bt.x0_device(dX)
+            gen = torch.Generator(device="cuda").manual_seed(int(77 * seed + case))
+            dX[:, 1:bt.n] += (0.01 * torch.randn(B, bt.n - 1, dtype=torch.float64, device="cuda", generator=gen)).to(dX.dtype)
+            dF.fill_(float("nan"))
+            bt.eval(dX, dF, dG)
+            torch.cuda.synchronize()
+            outs.append((dF[:, :bt.neF].clone(), dG[:, :bt.neG].clone(), flat[:off].clone(), flat[off + B * ld:].clone()))
+            bt.close()
+        what = (mission, N, B, dtype, pattern, off)
+        assert same(outs[0][0], outs[1][0]) and same(outs[0][1], outs[1][1]), what
+        assert torch_isnan(outs[1][2]).all() and torch_isnan(outs[1][3]).all(), what     # nothing written outside G

@@ -73,6 +73,8 @@ struct FgArgs {
     int  fused;            // 1 = the tile wave that arrives last at its trajectory's counter finalizes (one launch);
                            // 0 = finalize_kernel follows fg_kernel
     int  stagger;          // 1 = waves take an issue priority from their slot on the SIMD (launches whose waves all start together)
+    int  sub_nodes;        // 0 = a tile's Jacobian rows go through LDS all at once; 32 = in passes of 32 nodes (less LDS per
+                           // wave: 16 instead of 10 resident fp64 tile waves per CU); one node per lane, tile-per-workgroup kernel only
     int  nt_stores;        // 1 = the slab stream carries the non-temporal hint (outputs beyond the Infinity Cache)
     int  store_shape;      // measurement aid: 1 = launch store_shape_kernel (this launch's grid, tile order, LDS request and
                            // store flavour around nothing but the slab stores) instead of the evaluation
@@ -112,6 +114,8 @@ struct LaunchPlan {
     int fused;             // the last-arriving tile wave finalizes (one launch) vs finalize_kernel as a second launch
     int tail_count, tail_nt;   // the last tail_count trajectories in tiles of <= tail_nt nodes (0 = no tail)
     int stagger;           // issue priorities by SIMD slot (FgArgs::stagger)
+    int sub_nodes;         // Jacobian rows through LDS in passes of this many nodes (FgArgs::sub_nodes), 0 = whole tile
+    int single;            // one workgroup per trajectory, one launch (fg_single_kernel): a few short trajectories
 };
 // what the plan looks at: the launch's shape and the bytes it writes
 struct LaunchShape {
@@ -139,7 +143,10 @@ hipError_t launch_sum(const void *v, int B, int dtype, double *out, hipStream_t 
 
 // Initial guess of B trajectories straight into device rows (ref: problemS10::InitialCond /
 // problemG7::InitialCond); bounds likewise (ref: problem::setLimits).  One-time set-up kernels.
-hipError_t launch_x0(const FgArgs &a, int mission, int dtype, hipStream_t s);
+// tgrid: device table [2][N+1] of the node times t_k = t_(k-1) + dt, added up on the host (S10: dt = 20/N, then G7: dt =
+// 10/N) -- the node-parallel kernel, one workgroup per trajectory; nullptr = the serial reference form, one thread
+// per trajectory (bitwise the same rows)
+hipError_t launch_x0(const FgArgs &a, int mission, int dtype, const double *tgrid, hipStream_t s);
 struct BoundsArgs {
     void *xlow, *xupp; long ldx;
     void *Flow, *Fupp; long ldf;
@@ -151,9 +158,9 @@ struct BoundsArgs {
 hipError_t launch_bounds(const BoundsArgs &a, int dtype, hipStream_t s);
 
 // LDS bytes per workgroup of the fg kernel (for DESIGN.md / occupancy reporting)
-int fg_lds_bytes(int dtype, int nt = 0);        // nt = nodes per tile (0 = 64)
+int fg_lds_bytes(int dtype, int nt = 0, int sub_nodes = 0);        // nt = nodes per tile (0 = 64); sub_nodes: FgArgs::sub_nodes
 // LDS bytes to request at launch so that at most waves_per_cu workgroups share a CU (0 = no cap)
-int fg_lds_request(int dtype, int waves_per_cu, int nt = 0);
+int fg_lds_request(int dtype, int waves_per_cu, int nt = 0, int sub_nodes = 0);
 
 }  // namespace tolfg
 #endif

@@ -767,28 +767,48 @@ __device__ __forceinline__ void tile_body(const FgArgs &a, T *lds, int item, int
     if (a.needG) {
         // idle lanes (lane >= cnt) leave no row: the workgroup's LDS holds a.nt + 1 rows, not TN + 1; the second
         // component of a lane whose second node lies beyond the tile writes the spare row, which nobody reads
-        if (act[0]) {
-            T *row = lds + (lane + 1) * RS;          // rows follow one spare row (SlabStream)
-            if constexpr (NP == 1) {
+        if constexpr (NP == 1) {
+            // The rows go through LDS a.sub_nodes nodes at a time (0 = the whole tile at once): a tile of 52 fp64 nodes
+            // holds 14.8 KB of rows, which caps a CU at 10 resident tile waves; with 32-node passes the same LDS space
+            // (9.2 KB) serves the tile in two passes and 16 waves fit.  A pass is a sub-tile to the stream: 32 nodes of
+            // slabs are a whole number of 16-byte vectors for every element size and pattern, so the second pass starts
+            // at the same offset from a 16-byte boundary as the first and SlabStream::run streams it unchanged.  The
+            // lanes outside the pass idle through jacobian() (the launches this is for are not VALU-bound).
+            const int sub = a.sub_nodes > 0 ? a.sub_nodes : TN;
+            T *const gtile = stream.gslab;
+            for (int n0 = 0; n0 < cnt; n0 += sub) {          // wave-uniform: one or two passes
+                if (n0 > 0) __syncthreads();                 // the pass before has read its rows
+                const int c = min(sub, cnt - n0);
+                if (lane >= n0 && lane < n0 + c) {
+                    T *row = lds + (lane - n0 + 1) * RS;     // rows follow one spare row (SlabStream)
 #if defined(TOLFG_STAMPS) || defined(TOLFG_ABLATE)
-                if (TOLFG_VARIANT(a) & 256) {
+                    if (TOLFG_VARIANT(a) & 256) {
 #pragma unroll
-                    for (int i = 0; i < 32; i++) row[i] = s[i % NI];
-                } else
+                        for (int i = 0; i < 32; i++) row[i] = s[i % NI];
+                    } else
 #endif
-                nc.jacobian(f, row);
-                row[SL_ZERO] = T(0); row[SL_ONE] = T(1); row[SL_MONE] = T(-1);
-            } else {
+                    nc.jacobian(f, row);
+                    row[SL_ZERO] = T(0); row[SL_ONE] = T(1); row[SL_MONE] = T(-1);
+                }
+                __syncthreads();
+                TOLFG_STAMP(a, 3);
+                __builtin_amdgcn_sched_barrier(0);
+                stream.gslab = gtile + (long)SLABN * n0;
+                if (!(TOLFG_VARIANT(a) & 2048)) stream.run(lds, c, lane);
+            }
+        } else {
+            if (act[0]) {
+                T *row = lds + (lane + 1) * RS;
                 T *row1 = act[NP - 1] ? row + TILE * RS : lds;
                 nc.jacobian(f, RowPair{row, row1});
                 row[SL_ZERO] = T(0); row[SL_ONE] = T(1); row[SL_MONE] = T(-1);
                 row1[SL_ZERO] = T(0); row1[SL_ONE] = T(1); row1[SL_MONE] = T(-1);
             }
+            __syncthreads();
+            TOLFG_STAMP(a, 3);
+            __builtin_amdgcn_sched_barrier(0);
+            if (!(TOLFG_VARIANT(a) & 2048)) stream.run(lds, cnt, lane);
         }
-        __syncthreads();
-        TOLFG_STAMP(a, 3);
-        __builtin_amdgcn_sched_barrier(0);
-        if (!(TOLFG_VARIANT(a) & 2048)) stream.run(lds, cnt, lane);
         TOLFG_STAMP(a, 4);
     }
     TOLFG_STAMP(a, 5);
@@ -999,6 +1019,14 @@ __device__ __forceinline__ void run_tile(const FgArgs &a, T *lds, int item, int 
         pub.slot = a.partial + 2 * (long)item;
         pub.counter = a.counter + b;
     }
+    // The SNOPT callback (a.done) reads x where the caller keeps it, in host memory: every tile wave asks for the 23 values
+    // finalize_body reads (dt, node 0, node N) right away, so that whichever wave finalizes has them without a second
+    // PCIe round trip at the end (fg_single_kernel's wave 0 does the same).
+    T pre = T(0);
+    if (a.done && lane < 23) {
+        const T *x = static_cast<const T *>(a.X) + (long)b * a.ldx;
+        pre = x[lane <= 11 ? lane : NI * a.N + lane - 11];
+    }
     tile_body<T, MISSION, WIND, VEC, PAT, NT, NP>(a, lds, item, lane, sumT, sumP, pub);
     if (a.fused) {
         const unsigned old = __builtin_amdgcn_readfirstlane(pub.old);
@@ -1006,7 +1034,13 @@ __device__ __forceinline__ void run_tile(const FgArgs &a, T *lds, int item, int 
             if (lane == 0) __hip_atomic_store(pub.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             T st = T(0), sp = T(0);
             if (a.needF) sum_partials<T, true>(a.partial + 2 * (long)at.first, at.tiles, lane, st, sp, a.status);
-            finalize_body<T, MISSION, PAT>(a, b, lane, st, sp);
+            const T *edge = nullptr;
+            if (a.done) {                               // the wave's LDS rows have been streamed: the space is free
+                if (lane < 23) lds[lane] = pre;
+                __syncthreads();
+                edge = lds;
+            }
+            finalize_body<T, MISSION, PAT>(a, b, lane, st, sp, edge);
         }
     } else if (a.needF && lane == 0) {
         a.partial[2 * (long)item + 0] = (double)sumT;
@@ -1183,7 +1217,7 @@ hipError_t launch_vec(const FgArgs &a, int vec, dim3 grid, hipStream_t s, hipEve
     // Timing events ride on the dispatches themselves (hipExtLaunchKernelGGL: the kernel's own start / end
     // timestamps, no extra commands on the stream): t0 = start of fg_kernel, t1 = end of the evaluation's
     // last kernel (fg_kernel when fused, else finalize_kernel).
-    const unsigned lds = (unsigned)fg_lds_request(sizeof(T) == 8 ? 0 : 1, a.waves_per_cu, a.nt);
+    const unsigned lds = (unsigned)fg_lds_request(sizeof(T) == 8 ? 0 : 1, a.waves_per_cu, a.nt, NP == 1 ? a.sub_nodes : 0);
     hipEvent_t fg_end = a.fused ? t1 : nullptr;
     auto go = [&](auto kernel, dim3 g, unsigned ldsz, hipEvent_t st, hipEvent_t en) {
         if (st || en) hipExtLaunchKernelGGL(kernel, g, dim3(TILE), ldsz, s, st, en, 0, a);
@@ -1237,76 +1271,226 @@ hipError_t launch_mission(const FgArgs &a, int mission, int wind, int vec, dim3 
 
 
 // ---- set-up kernels: initial guess and bounds generated on the device.
-// One thread per trajectory walks its nodes in order, exactly like the host code in setup.cpp does
-// (the course unwrap and the control rates depend on the previous node).
+// ref: problemS10::InitialCond src/problemS10.cpp:19-219, problemG7::InitialCond src/problemG7.cpp:19-217 (restated in
+// setup.cpp::initial_guess, whose operations these kernels repeat one for one).
 __device__ __forceinline__ double atan2_t(double y, double x) { return atan2(y, x); }
 
+// Everything InitialCond computes at ONE node from the node's time alone: position, air-relative speed, the course
+// before it is made continuous, flight-path angle, bank, lift coefficient, thrust.
+struct X0Node { double p[3], Va, chi_raw, gam, phi, CL, thrust; };
+
+// FAST: atan2(+-0, x > 0) is +-0 by definition, and both missions' guesses have such arguments at every node (no vertical
+// motion: az = 0; G7 flies a straight line: ay = 0) -- the node-parallel kernel skips the library call there; the serial
+// reference form always calls it, and the two are compared bit for bit.
+template <bool FAST> __device__ __forceinline__ double x0_atan2(double y, double x)
+{
+    if (FAST && y == 0.0 && x > 0.0) return y;
+    return atan2_t(y, x);
+}
+
+template <bool FAST>
+__device__ __forceinline__ X0Node x0_node(bool loiter, double t, const TrajDev &tr, const AcCoef &ac, double cd, double sd)
+{
+    constexpr double kRho = 1.2682, kPi = 3.14159265358979323846;
+    const double tfinal = loiter ? 20.0 : 10.0;
+    const double ax = loiter ? 100.0 : 40.0, ay = loiter ? 100.0 : 0.0, az = 0.0;
+    const double w = 2.0 * kPi / tfinal;
+    const double s = sin(w * t), c = cos(w * t);     // (sincos() shares the reduction but differs from these in the last bit at some nodes)
+    X0Node o;
+    double v[3], acc[3];
+    if (loiter) {
+        o.p[0] = ax * s - ax + tr.xi;   o.p[1] = -ay * c + tr.yi;      o.p[2] = az * c - az + tr.zi;
+        v[0] = w * ax * c;              v[1] = w * ay * s;             v[2] = -w * az * s;
+        acc[0] = -w * w * ax * s;       acc[1] = w * w * ay * c;       acc[2] = -w * w * az * c;
+    } else {
+        const double px = ax / tfinal * t + tr.xi, py = -ay * c + ay + tr.yi;
+        o.p[0] = cd * px - sd * py;
+        o.p[1] = sd * px + cd * py;
+        o.p[2] = az * c - az + tr.zi;
+        v[0] = ax / tfinal;             v[1] = ay * w * s;             v[2] = -az * w * s;
+        acc[0] = 0.0;                   acc[1] = ay * w * w * c;       acc[2] = -az * w * w * c;
+    }
+    o.Va = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    o.chi_raw = x0_atan2<FAST>(v[1], v[0]) + (loiter ? 0.0 : tr.chi_d);
+    const double h2 = v[0] * v[0] + v[1] * v[1];
+    o.gam = (FAST && v[2] == 0.0 && h2 > 0.0) ? -v[2] : atan2_t(-v[2], sqrt(h2));       // atan2(+-0, sqrt(h2) > 0) = +-0
+    const double u[3] = {v[0] / o.Va, v[1] / o.Va, v[2] / o.Va};
+    const double sf[3] = {acc[0], acc[1], acc[2] - kGrav};
+    const double n0 = -sf[0] * (u[0] * u[0] - 1.0) - u[0] * u[1] * sf[1] - u[0] * u[2] * sf[2];
+    const double n1 = -sf[1] * (u[1] * u[1] - 1.0) - u[0] * u[1] * sf[0] - u[1] * u[2] * sf[2];
+    const double n2 = -sf[2] * (u[2] * u[2] - 1.0) - u[0] * u[2] * sf[0] - u[1] * u[2] * sf[1];
+    const double nmag = sqrt(n0 * n0 + n1 * n1 + n2 * n2);
+    const double l0 = -n0 / nmag, l1 = -n1 / nmag, l2 = -n2 / nmag;
+    o.phi = atan2_t(l0 * u[1] - l1 * u[0], l2);
+    o.CL = 2.0 * (ac.mm * nmag) / (kRho * o.Va * o.Va * ac.SS);
+    const double drag = 0.5 * kRho * o.Va * o.Va * ac.SS * (ac.Cd0 + o.CL * o.CL / (kPi * ac.AR * ac.ee));
+    o.thrust = ac.mm * (u[0] * sf[0] + u[1] * sf[1] + u[2] * sf[2]) + drag;
+    return o;
+}
+
+// The one step of InitialCond that looks at the node before: the course is kept continuous from node to node.
+__device__ __forceinline__ double x0_unwrap(double chi, double chi_prev)
+{
+    constexpr double kPi = 3.14159265358979323846;
+    double jump = chi - chi_prev;
+    while (jump < -kPi || jump > kPi) {
+        if (jump < -kPi) chi = chi + 2.0 * kPi * ceil((-kPi - jump) / (2.0 * kPi));
+        if (jump > kPi) chi = chi + 2.0 * kPi * floor((kPi - jump) / (2.0 * kPi));
+        jump = chi - chi_prev;
+    }
+    return chi;
+}
+
+// Serial form: one thread per trajectory walks its nodes in order, exactly like the host code.  Kept as the reference the
+// node-parallel kernel is checked against bit for bit (TOLFG_X0_SERIAL=1, tests/test_device_setup.py); 353 us for 8192
+// trajectories of 201 nodes, longer than the evaluation it feeds.
 template <typename T, int MISSION>
-__global__ void x0_kernel(const FgArgs a)
+__global__ void x0_serial_kernel(const FgArgs a)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= a.B) return;
-    constexpr double kRho = 1.2682, kPi = 3.14159265358979323846;
     const int N = a.N;
     const TrajDev tr = a.traj[b];
     const bool loiter = (MISSION == MISSION_MIXED ? tr.mission : MISSION) == MISSION_S10;
     const AcCoef ac = a.ac[tr.ac];
     T *x = static_cast<T *>(const_cast<void *>(a.X)) + (long)b * a.ldx;
     const double tfinal = loiter ? 20.0 : 10.0;
-    const double ax = loiter ? 100.0 : 40.0, ay = loiter ? 100.0 : 0.0, az = 0.0;
     const double dt = tfinal / N;
-    const double w = 2.0 * kPi / tfinal;
-    const double cd = cos(tr.chi_d), sd = sin(tr.chi_d);
+    const double cd = tr.cchi, sd = tr.schi;       // cos / sin of chi_d as the host formed them (setup.cpp::initial_guess uses the same)
     double t = 0.0, chi_prev = 0.0, phi_prev = 0.0, CL_prev = 0.0, dphi_last = 0.0, dCL_last = 0.0;
     for (int k = 0; k <= N; ++k, t = t + dt) {
-        const double s = sin(w * t), c = cos(w * t);
-        double p[3], v[3], acc[3];
-        if (loiter) {
-            p[0] = ax * s - ax + tr.xi;     p[1] = -ay * c + tr.yi;        p[2] = az * c - az + tr.zi;
-            v[0] = w * ax * c;              v[1] = w * ay * s;             v[2] = -w * az * s;
-            acc[0] = -w * w * ax * s;       acc[1] = w * w * ay * c;       acc[2] = -w * w * az * c;
-        } else {
-            const double px = ax / tfinal * t + tr.xi, py = -ay * c + ay + tr.yi;
-            p[0] = cd * px - sd * py;
-            p[1] = sd * px + cd * py;
-            p[2] = az * c - az + tr.zi;
-            v[0] = ax / tfinal;             v[1] = ay * w * s;             v[2] = -az * w * s;
-            acc[0] = 0.0;                   acc[1] = ay * w * w * c;       acc[2] = -az * w * w * c;
-        }
-        const double Va = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
-        double chi = atan2_t(v[1], v[0]) + (loiter ? 0.0 : tr.chi_d);
-        const double gam = atan2_t(-v[2], sqrt(v[0] * v[0] + v[1] * v[1]));
-        if (k > 0) {
-            double jump = chi - chi_prev;
-            while (jump < -kPi || jump > kPi) {
-                if (jump < -kPi) chi = chi + 2.0 * kPi * ceil((-kPi - jump) / (2.0 * kPi));
-                if (jump > kPi) chi = chi + 2.0 * kPi * floor((kPi - jump) / (2.0 * kPi));
-                jump = chi - chi_prev;
-            }
-        }
-        const double u[3] = {v[0] / Va, v[1] / Va, v[2] / Va};
-        const double sf[3] = {acc[0], acc[1], acc[2] - kGrav};
-        const double n0 = -sf[0] * (u[0] * u[0] - 1.0) - u[0] * u[1] * sf[1] - u[0] * u[2] * sf[2];
-        const double n1 = -sf[1] * (u[1] * u[1] - 1.0) - u[0] * u[1] * sf[0] - u[1] * u[2] * sf[2];
-        const double n2 = -sf[2] * (u[2] * u[2] - 1.0) - u[0] * u[2] * sf[0] - u[1] * u[2] * sf[1];
-        const double nmag = sqrt(n0 * n0 + n1 * n1 + n2 * n2);
-        const double l0 = -n0 / nmag, l1 = -n1 / nmag, l2 = -n2 / nmag;
-        const double phi = atan2_t(l0 * u[1] - l1 * u[0], l2);
-        const double CL = 2.0 * (ac.mm * nmag) / (kRho * Va * Va * ac.SS);
-        const double drag = 0.5 * kRho * Va * Va * ac.SS * (ac.Cd0 + CL * CL / (kPi * ac.AR * ac.ee));
-        const double thrust = ac.mm * (u[0] * sf[0] + u[1] * sf[1] + u[2] * sf[2]) + drag;
+        const X0Node o = x0_node<false>(loiter, t, tr, ac, cd, sd);
+        const double chi = k > 0 ? x0_unwrap(o.chi_raw, chi_prev) : o.chi_raw;
         T *nd = x + 11 * k + 1;
-        dphi_last = k ? (phi - phi_prev) / dt : 0.0;
-        dCL_last = k ? (CL - CL_prev) / dt : 0.0;
-        nd[0] = T(p[0]); nd[1] = T(p[1]); nd[2] = T(p[2]);
-        nd[3] = T(Va); nd[4] = T(gam); nd[5] = T(chi); nd[6] = T(phi); nd[7] = T(CL);
-        nd[8] = T(dphi_last); nd[9] = T(dCL_last); nd[10] = T(thrust);
-        chi_prev = chi; phi_prev = phi; CL_prev = CL;
+        dphi_last = k ? (o.phi - phi_prev) / dt : 0.0;
+        dCL_last = k ? (o.CL - CL_prev) / dt : 0.0;
+        nd[0] = T(o.p[0]); nd[1] = T(o.p[1]); nd[2] = T(o.p[2]);
+        nd[3] = T(o.Va); nd[4] = T(o.gam); nd[5] = T(chi); nd[6] = T(o.phi); nd[7] = T(o.CL);
+        nd[8] = T(dphi_last); nd[9] = T(dCL_last); nd[10] = T(o.thrust);
+        chi_prev = chi; phi_prev = o.phi; CL_prev = o.CL;
     }
     x[0] = T(dt);
     if (loiter) {   // src/problemS10.cpp:210-211
         x[9] = T(dphi_last);
         x[10] = T(dCL_last);
+    }
+}
+
+// Node-parallel form: one workgroup per trajectory, one thread per node, X0_NODES nodes per pass.  Only three things in
+// InitialCond look at the node before, and each has a parallel form whose result is the serial one bit for bit:
+//   * the node's time is the running sum t = t + dt: the host adds it up once per mission (the same IEEE additions)
+//     and the kernel reads t_k from that table (tgrid);
+//   * the course is made continuous against the PREVIOUS node's continuous course: every node first takes a guess --
+//     its own course plus 2 pi times the number of wraps before it (a scan over the nodes of the jumps of the raw
+//     course) -- and then runs the reference's own step (x0_unwrap) against its neighbour's guess; where every node
+//     reproduces its guess, the guesses ARE the serial result (induction from node 0), otherwise -- never seen -- one
+//     thread redoes the pass serially;
+//   * the control rates are differences to the previous node's bank and lift coefficient: a neighbour read in LDS.
+// The rows leave through an LDS image of the pass (node-major, as in memory) with coalesced stores.
+constexpr int X0_NODES = 256;
+
+template <typename T, int MISSION>
+__global__ __launch_bounds__(X0_NODES) void x0_kernel(const FgArgs a, const double *tgrid)
+{
+    constexpr double kPi = 3.14159265358979323846;
+    __shared__ double raw_s[X0_NODES + 1], chi_s[X0_NODES + 1], phi_s[X0_NODES + 1], CL_s[X0_NODES + 1];   // [0] = the node before the pass
+    __shared__ int wraps_s[X0_NODES / TILE];
+    __shared__ int redo_s;
+    __shared__ T img[X0_NODES * NI];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid % TILE, wv = tid / TILE;
+    const int N = a.N;
+    const TrajDev tr = a.traj[b];
+    const bool loiter = (MISSION == MISSION_MIXED ? tr.mission : MISSION) == MISSION_S10;
+    const AcCoef ac = a.ac[tr.ac];
+    T *x = static_cast<T *>(const_cast<void *>(a.X)) + (long)b * a.ldx;
+    const double dt = (loiter ? 20.0 : 10.0) / N;
+    const double cd = tr.cchi, sd = tr.schi;
+    const double *tg = tgrid + (loiter ? 0 : N + 1);
+    int wraps_before = 0;                       // 2 pi multiples the node before the pass carries (every thread keeps its copy)
+    if (tid == 0) { raw_s[0] = 0.0; chi_s[0] = 0.0; phi_s[0] = 0.0; CL_s[0] = 0.0; redo_s = 0; x[0] = T(dt); }
+    double dphi = 0.0, dCL = 0.0;
+    for (int k0 = 0; k0 <= N; k0 += X0_NODES) {
+        const int k = k0 + tid;
+        const int cnt = min(X0_NODES, N + 1 - k0);
+        const bool act = tid < cnt;
+        X0Node o{};
+        if (act) {
+            o = x0_node<true>(loiter, tg[k], tr, ac, cd, sd);
+            raw_s[tid + 1] = o.chi_raw; phi_s[tid + 1] = o.phi; CL_s[tid + 1] = o.CL;
+        }
+        __syncthreads();
+        // wraps up to and including this node: +1 where the raw course falls by more than pi, -1 where it rises by more
+        int d = 0;
+        if (act && k > 0) {
+            const double J = o.chi_raw - raw_s[tid];
+            d = J < -kPi ? 1 : (J > kPi ? -1 : 0);
+        }
+        int m = d;
+#pragma unroll
+        for (int sh = 1; sh < TILE; sh <<= 1) {
+            const int up = __shfl_up(m, sh, TILE);
+            if (lane >= sh) m += up;
+        }
+        if (lane == TILE - 1) wraps_s[wv] = m;
+        __syncthreads();
+        for (int q = 0; q < wv; q++) m += wraps_s[q];
+        int pass_wraps = 0;
+        for (int q = 0; q < X0_NODES / TILE; q++) pass_wraps += wraps_s[q];
+        m += wraps_before;
+        double chi = o.chi_raw;
+        if (m != 0) chi = chi + 2.0 * kPi * (double)m;
+        if (act) chi_s[tid + 1] = chi;
+        __syncthreads();
+        // the reference's own step against the neighbour's guess
+        if (act && k > 0 && x0_unwrap(o.chi_raw, chi_s[tid]) != chi) redo_s = 1;
+        __syncthreads();
+        if (redo_s) {                           // not seen in practice: the pass again, serially, by one thread
+            if (tid == 0) {
+                for (int j = 0; j < cnt; j++) chi_s[j + 1] = (k0 + j) > 0 ? x0_unwrap(raw_s[j + 1], chi_s[j]) : raw_s[j + 1];
+            }
+            __syncthreads();
+            if (act) chi = chi_s[tid + 1];
+        }
+        if (act) {
+            dphi = k ? (o.phi - phi_s[tid]) / dt : 0.0;
+            dCL = k ? (o.CL - CL_s[tid]) / dt : 0.0;
+            T *nd = img + NI * tid;
+            nd[0] = T(o.p[0]); nd[1] = T(o.p[1]); nd[2] = T(o.p[2]);
+            nd[3] = T(o.Va); nd[4] = T(o.gam); nd[5] = T(chi); nd[6] = T(o.phi); nd[7] = T(o.CL);
+            nd[8] = T(dphi); nd[9] = T(dCL); nd[10] = T(o.thrust);
+        }
+        __syncthreads();
+        // the pass's NI * cnt elements start at x[1 + NI * k0]: one element (two, three in fp32) up to the next 16-byte
+        // boundary, then whole vectors, then the rest
+        {
+            constexpr int GV = 16 / (int)sizeof(T);
+            typedef typename Vec<T, GV>::type vec;
+            T *dst = x + 1 + (long)NI * k0;
+            const int E = NI * cnt;
+            const int head = min(E, (int)((GV - (reinterpret_cast<unsigned long long>(dst) / sizeof(T)) % GV) % GV));
+            const int nv = (E - head) / GV;
+            if (tid < head) dst[tid] = img[tid];
+            for (int i = tid; i < nv; i += X0_NODES) {
+                vec v;
+#pragma unroll
+                for (int c = 0; c < GV; c++) v[c] = img[head + GV * i + c];
+                *reinterpret_cast<vec *>(dst + head + GV * i) = v;
+            }
+            const int done_ = head + GV * nv;
+            if (tid < E - done_) dst[done_ + tid] = img[done_ + tid];
+        }
+        // the last node of this pass is "the node before" of the next
+        const double craw = raw_s[cnt], cchi = chi_s[cnt], cphi = phi_s[cnt], cCL = CL_s[cnt];
+        // a redone pass may have left the guess's wrap count behind: take it from the continuous course itself
+        wraps_before = redo_s ? (int)rint((cchi - craw) / (2.0 * kPi)) : wraps_before + pass_wraps;
+        __syncthreads();
+        if (tid == 0) { raw_s[0] = craw; chi_s[0] = cchi; phi_s[0] = cphi; CL_s[0] = cCL; redo_s = 0; }
+        if (loiter && k == N) {                 // src/problemS10.cpp:210-211: node 0's rates are overwritten by node N's
+            // (the stores of node 0's row left before a barrier of this workgroup, so these land after them)
+            x[9] = T(dphi);
+            x[10] = T(dCL);
+        }
+        __syncthreads();
     }
 }
 
@@ -1399,6 +1583,8 @@ hipError_t launch_fg(const FgArgs &a, int mission, int wind, int dtype, int vec,
     if (a.N < 1 || a.nt < 4 || a.nt > (dtype == 1 ? 2 * TILE : TILE) || (a.nt & 3) || a.tiles != (a.N + a.nt - 1) / a.nt || !a.partial)
         return hipErrorInvalidValue;
     if (packed && (a.single || vec != 4)) return hipErrorInvalidValue;
+    // rows through LDS in passes: 32 nodes of slabs are whole 16-byte vectors for every element size and pattern
+    if (a.sub_nodes != 0 && (a.sub_nodes != 32 || a.single || packed)) return hipErrorInvalidValue;
     if ((a.fused || a.done) && !a.counter) return hipErrorInvalidValue;
     if (a.done && !a.fused && !a.single) return hipErrorInvalidValue;     // finalize_kernel would still be running
     if (a.tail_count < 0 || a.tail_count > a.B) return hipErrorInvalidValue;
@@ -1434,18 +1620,31 @@ hipError_t launch_sum(const void *v, int B, int dtype, double *out, hipStream_t 
     return hipGetLastError();
 }
 
-hipError_t launch_x0(const FgArgs &a, int mission, int dtype, hipStream_t s)
+hipError_t launch_x0(const FgArgs &a, int mission, int dtype, const double *tgrid, hipStream_t s)
 {
     if (a.B <= 0) return hipSuccess;
-    const dim3 grid((a.B + 63) / 64), block(64);
+    if (!tgrid) {       // the serial reference form (measurements, bitwise A/B)
+        const dim3 grid((a.B + 63) / 64), block(64);
+        if (dtype == 0) {
+            if (mission == MISSION_S10)     hipLaunchKernelGGL((x0_serial_kernel<double, MISSION_S10>), grid, block, 0, s, a);
+            else if (mission == MISSION_G7) hipLaunchKernelGGL((x0_serial_kernel<double, MISSION_G7>), grid, block, 0, s, a);
+            else                            hipLaunchKernelGGL((x0_serial_kernel<double, MISSION_MIXED>), grid, block, 0, s, a);
+        } else {
+            if (mission == MISSION_S10)     hipLaunchKernelGGL((x0_serial_kernel<float, MISSION_S10>), grid, block, 0, s, a);
+            else if (mission == MISSION_G7) hipLaunchKernelGGL((x0_serial_kernel<float, MISSION_G7>), grid, block, 0, s, a);
+            else                            hipLaunchKernelGGL((x0_serial_kernel<float, MISSION_MIXED>), grid, block, 0, s, a);
+        }
+        return hipGetLastError();
+    }
+    const dim3 grid(a.B), block(X0_NODES);
     if (dtype == 0) {
-        if (mission == MISSION_S10)     hipLaunchKernelGGL((x0_kernel<double, MISSION_S10>), grid, block, 0, s, a);
-        else if (mission == MISSION_G7) hipLaunchKernelGGL((x0_kernel<double, MISSION_G7>), grid, block, 0, s, a);
-        else                            hipLaunchKernelGGL((x0_kernel<double, MISSION_MIXED>), grid, block, 0, s, a);
+        if (mission == MISSION_S10)     hipLaunchKernelGGL((x0_kernel<double, MISSION_S10>), grid, block, 0, s, a, tgrid);
+        else if (mission == MISSION_G7) hipLaunchKernelGGL((x0_kernel<double, MISSION_G7>), grid, block, 0, s, a, tgrid);
+        else                            hipLaunchKernelGGL((x0_kernel<double, MISSION_MIXED>), grid, block, 0, s, a, tgrid);
     } else {
-        if (mission == MISSION_S10)     hipLaunchKernelGGL((x0_kernel<float, MISSION_S10>), grid, block, 0, s, a);
-        else if (mission == MISSION_G7) hipLaunchKernelGGL((x0_kernel<float, MISSION_G7>), grid, block, 0, s, a);
-        else                            hipLaunchKernelGGL((x0_kernel<float, MISSION_MIXED>), grid, block, 0, s, a);
+        if (mission == MISSION_S10)     hipLaunchKernelGGL((x0_kernel<float, MISSION_S10>), grid, block, 0, s, a, tgrid);
+        else if (mission == MISSION_G7) hipLaunchKernelGGL((x0_kernel<float, MISSION_G7>), grid, block, 0, s, a, tgrid);
+        else                            hipLaunchKernelGGL((x0_kernel<float, MISSION_MIXED>), grid, block, 0, s, a, tgrid);
     }
     return hipGetLastError();
 }
@@ -1460,17 +1659,20 @@ hipError_t launch_bounds(const BoundsArgs &a, int dtype, hipStream_t s)
     return hipGetLastError();
 }
 
-int fg_lds_bytes(int dtype, int nt)
+int fg_lds_bytes(int dtype, int nt, int sub_nodes)
 {
-    // a spare row and nt rows of RS elements (the x window, 11*nt + 10 elements at most, is staged in the same space first)
-    const int rows = nt > 0 && nt <= 2 * TILE ? nt : TILE;
-    return (((rows + 1) * RS * (dtype == 0 ? 8 : 4)) + 15) & ~15;
+    // a spare row and the rows of one pass, RS elements each; the x window (11*nt + 9 elements, rounded up to whole
+    // 16-byte vectors) is staged in the same space first
+    const int tile = nt > 0 && nt <= 2 * TILE ? nt : TILE;
+    const int rows = sub_nodes > 0 && sub_nodes < tile ? sub_nodes : tile;
+    const int elems = (rows + 1) * RS > NI * tile + 12 ? (rows + 1) * RS : NI * tile + 12;
+    return ((elems * (dtype == 0 ? 8 : 4)) + 15) & ~15;
 }
 
-int fg_lds_request(int dtype, int waves_per_cu, int nt)
+int fg_lds_request(int dtype, int waves_per_cu, int nt, int sub_nodes)
 {
     // LDS per workgroup such that at most `waves_per_cu` one-wave workgroups fit the CU's 160 KiB
-    const int need = fg_lds_bytes(dtype, nt);
+    const int need = fg_lds_bytes(dtype, nt, sub_nodes);
     if (waves_per_cu <= 0) return need;
     int cap = (160 * 1024 / waves_per_cu) & ~15;
     if (cap > 64 * 1024) cap = 64 * 1024;

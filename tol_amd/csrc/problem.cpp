@@ -123,6 +123,7 @@ batch::batch(const std::string &mission, const std::string &root, const std::vec
     if (env_int("TOLFG_NT_STORES", 0, 1, &v)) nt_forced_ = v;
     if (env_int("TOLFG_XCD", 0, 1, &v)) xcd_forced_ = v;
     if (env_int("TOLFG_STAGGER", 0, 1, &v)) stagger_forced_ = v;
+    if (env_int("TOLFG_SUB_NODES", 0, 32, &v)) sub_forced_ = v >= 32 ? 32 : 0;
     if (const char *e = std::getenv("TOLFG_TAIL")) {        // "count:nt", count 0 = no tail
         tail_forced_ = std::max(0, std::atoi(e));
         if (const char *c = std::strchr(e, ':')) tail_nt_forced_ = std::min(tile_ok(std::atoi(c + 1)), kTileNodes);
@@ -171,6 +172,7 @@ batch::~batch()
     if (d_counter_) (void)hipFree(d_counter_);
     if (h_status_) (void)hipHostFree(h_status_);
     if (d_grid_) (void)hipFree(d_grid_);
+    if (d_tgrid_) (void)hipFree(d_tgrid_);
     for (hipEvent_t e : ev_) if (e) (void)hipEventDestroy(e);
 }
 
@@ -304,7 +306,7 @@ void batch::eval(int B, const void *dX, long ldx, void *dF, long ldf, void *dG, 
     // workgroup (measured per call: ts=100 24.7 vs 29.2 us, ts=200 29.7 vs 33.1 us; at ts=500, 8 waves
     // per workgroup, the tile-per-workgroup path is as fast, so the single form is used up to ts = 256)
     static const bool no_single = std::getenv("TOLFG_NO_SINGLE_LAUNCH") != nullptr;
-    a.single = (!no_single && B <= 8 && a.N <= 256 && mission_ != MISSION_MIXED) ? 1 : 0;
+    static const bool force_single = std::getenv("TOLFG_FORCE_SINGLE_LAUNCH") != nullptr;    // measurement: the one-workgroup form wherever it can run
     const double out_bytes = (double)elem_size() * B * ((needF ? sz_.neF : 0) + (needG ? sz_.neG : 0));
     // 16-byte window loads and defect stores need the rows of X and F on 16-byte boundaries; the slab stream
     // copes with any position of G (the waves shift their streams)
@@ -312,6 +314,7 @@ void batch::eval(int B, const void *dX, long ldx, void *dF, long ldf, void *dG, 
     const bool aligned = (reinterpret_cast<uintptr_t>(dX) % 16 == 0) && (ldx % vmax == 0) &&
                          (!needF || ((reinterpret_cast<uintptr_t>(dF) % 16 == 0) && (ldf % vmax == 0)));
     const LaunchPlan lp = plan_launch(LaunchShape{B, a.N, dtype_, a.pattern, mission_, aligned ? 1 : 0, out_bytes});
+    a.single = (!no_single && (lp.single || (force_single && B <= 8 && a.N <= 256 && mission_ != MISSION_MIXED))) ? 1 : 0;
     int max_nt = a.single ? 0 : (tile_nodes_forced_ > 0 ? tile_nodes_forced_ : lp.max_nt);
     if (!aligned && max_nt > 64) max_nt = 64;          // two nodes per lane (fp32 tiles beyond 64 nodes) need 16-byte rows
     plan_tiles(a.N, dtype_, max_nt, &a.tiles, &a.nt);
@@ -360,6 +363,7 @@ void batch::eval(int B, const void *dX, long ldx, void *dF, long ldf, void *dG, 
     a.waves_per_cu = waves_forced_ ? waves_per_cu_ : lp.waves_per_cu;
     a.nt_stores = nt_forced_ >= 0 ? nt_forced_ : lp.nt_stores;
     a.stagger = (stagger_forced_ >= 0 ? stagger_forced_ : lp.stagger) && !a.single ? 1 : 0;
+    a.sub_nodes = (!a.single && a.nt > 32 && a.nt <= kTileNodes) ? (sub_forced_ >= 0 ? sub_forced_ : lp.sub_nodes) : 0;
     a.xcd_chunk = ((xcd_forced_ >= 0 ? xcd_forced_ : lp.xcd) && !a.single) ? (int)(a.tail_count ? body / 8 : (W + 7) / 8) : 0;
     a.X = dX; a.ldx = ldx; a.F = dF; a.ldf = ldf; a.G = dG; a.ldg = ldg;
     a.wind = dWind; a.traj = d_traj_;
@@ -408,7 +412,21 @@ void batch::x0_device(int B, void *dX, long ldx, hipStream_t stream)
     if (!uploaded_) upload();
     FgArgs a = args_;
     a.X = dX; a.ldx = ldx; a.traj = d_traj_; a.B = B;
-    check(launch_x0(a, mission_, dtype_, stream), "launch x0");
+    const bool serial = std::getenv("TOLFG_X0_SERIAL") != nullptr;      // measurement / bitwise A/B: the serial reference form
+    if (!serial && !d_tgrid_) {
+        // node times exactly as InitialCond forms them: t = t + dt from 0 (ref: src/problemS10.cpp:60-64)
+        const int N = sz_.N;
+        std::vector<double> tg(2 * (size_t)(N + 1));
+        for (int m = 0; m < 2; ++m) {
+            const double dt = (m == 0 ? 20.0 : 10.0) / N;
+            double t = 0.0;
+            for (int k = 0; k <= N; ++k, t = t + dt) tg[(size_t)m * (N + 1) + k] = t;
+        }
+        check(hipSetDevice(device_), "hipSetDevice");
+        check(hipMalloc(reinterpret_cast<void **>(&d_tgrid_), sizeof(double) * tg.size()), "hipMalloc(tgrid)");
+        check(hipMemcpy(d_tgrid_, tg.data(), sizeof(double) * tg.size(), hipMemcpyHostToDevice), "hipMemcpy(tgrid)");
+    }
+    check(launch_x0(a, mission_, dtype_, serial ? nullptr : d_tgrid_, stream), "launch x0");
 }
 
 void batch::bounds_device(int B, void *dXlow, void *dXupp, long ldx, void *dFlow, void *dFupp, long ldf, hipStream_t stream)

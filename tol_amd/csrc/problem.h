@@ -98,6 +98,7 @@ private:
     std::vector<hipEvent_t> ev_;
     size_t ev_used_ = 0;
     void *d_grid_ = nullptr;
+    double *d_tgrid_ = nullptr;         // node times of the initial guess, [2][N+1] (x0_device)
     std::vector<double> grid_host_;
     double *d_partial_ = nullptr;
     long partial_cap_ = 0;
@@ -110,6 +111,7 @@ private:
     bool partial_dirty_ = false;        // the partial slots hold a two-launch evaluation's sums (not "empty")
     int tail_forced_ = -1, tail_nt_forced_ = 0;   // TOLFG_TAIL=count:nt overrides the finer-tiled tail (measurements)
     int xcd_forced_ = -1;               // TOLFG_XCD=0/1 overrides the tile order (measurements)
+    int sub_forced_ = -1;               // TOLFG_SUB_NODES=0/32 overrides the LDS passes of a tile's rows (measurements)
     int stagger_forced_ = -1;           // TOLFG_STAGGER=0/1 overrides the issue-priority stagger (measurements)
     int ntraj_ = 0, cap_ = 0;
     hipStream_t last_stream_ = nullptr;  // stream of the last evaluation: moving to another one drains it first (stream contract)
