@@ -136,7 +136,8 @@ def make_trajectories(tol_amd, B, first_index, mission="S10", n_aircraft=1):
 
 
 def make_inputs(bt, torch, B, seed, buffers):
-    """X buffers in HBM: initial guesses generated on the device (tolfg_batch_x0_device) + 5 % noise; the
+    """F and G: Batch.alloc -- G from the library's placement-probing allocator (tolfg_batch_alloc_outputs; the record's
+    `placement` holds the candidates' probe times).  X buffers in HBM: initial guesses generated on the device (tolfg_batch_x0_device) + 5 % noise; the
     further buffers hold the same trajectories' vectors rotated by whole rows of the SAME mission/air-frame
     class (10 rows), so that every row stays a valid input of its trajectory and no step re-reads a cached X."""
     dX, dF, dG = bt.alloc(B)
@@ -194,7 +195,8 @@ def device_record(tol_amd, torch, cfg, workload, mission, aircraft, ts, B, dtype
            "ms_per_step": 1e3 * wall / steps, "node_evals_per_s": B * ts * steps / wall,
            "eval_us": 1e3 * avg_ms, "eval_us_instrumented": 1e3 * inst_ms, "eval_min_us_instrumented": 1e3 * inst_min_ms, "launches_per_step": 1,
            "algorithmic_bytes": alg, "achieved_GBs": gbs,
-           "frac_of_hbm_peak": gbs / HBM_PEAK_GBS, "frac_of_box_fill": gbs / box_fill(torch, dF.device)}
+           "frac_of_hbm_peak": gbs / HBM_PEAK_GBS, "frac_of_box_fill": gbs / box_fill(torch, dF.device),
+           "placement": getattr(bt, "placement", None)}
     if B > 8:       # callback-sized launches take the one-workgroup-per-trajectory kernel: no stream shape to calibrate
         shape_gbs, shape_us = store_shape_rate(bt, torch, dXs, dF, dG, B, ts, 104)
         rec.update(box_stream_shape_GBs=shape_gbs, box_stream_shape_us=shape_us, frac_of_box_stream_shape=gbs / shape_gbs)
@@ -449,7 +451,8 @@ def sharded_run(tol_amd, job, mission, aircraft, ts, dtype, pattern, per_gpu, gl
     if world > 1:      # every rank's shard arrived in place, in global trajectory order
         mine = obj[last].to(allobj[last].device)
         assert torch.equal(allobj[last][rank * Bmax:(rank + 1) * Bmax], mine), "gathered objectives are out of order"
-    out = {"B": B, "total": total, "scaling": scaling, "x_buffers": len(dXs), "buffers_reused": reused}
+    out = {"B": B, "total": total, "scaling": scaling, "x_buffers": len(dXs), "buffers_reused": reused,
+           "placement": getattr(bt, "placement", None)}
     # the gather alone (N > 1): synchronous all-gathers of the same buffers, nothing else in flight
     gather_us = 0.0
     if world > 1:
@@ -520,6 +523,7 @@ def stated_config_records(tol_amd, job, x_buffers, keep=None):
                      "frac_of_hbm_peak": alg_total / (r["kern_ms"] * 1e-3) / 1e9 / (HBM_PEAK_GBS * world),
                      "frac_of_hbm_peak_whole_step": alg_total / (r["elapsed"] / steps) / 1e9 / (HBM_PEAK_GBS * world),
                      "warmup_steps_run": r["warmup_steps_run"], "box_fill_GBs": r["box_fill_GBs"],
+                     "placement": r["placement"],
                      "buffers": ("the headline's batch object and buffers (the same workload: a second, independent timed region on the "
                                  "same allocation)" if r["buffers_reused"] else "its own allocation"),
                      "frac_of_box_fill": alg_total / (r["kern_ms"] * 1e-3) / 1e9 / (r["box_fill_GBs"] * world),
@@ -682,6 +686,7 @@ def main():
                                           f"start offsets; one F+G launch + objective gather per step",
                        "mission": args.mission, "aircraft": "+".join(aircraft), "ts": args.ts, "pattern": args.pattern,
                        "batch_per_gpu": B, "global_batch": total, "x_buffers": r["x_buffers"],
+                       "output_placement": r["placement"],
                        "parallelism": (f"batch-sharded x{world}, {backend} all-gather of objectives") if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,

@@ -45,6 +45,9 @@ enum {
                                 tolfg_set_wind_grid instead of the reference's MongoDB cache          */
     TOLFG_WIND_TABLE = 99    /* caller-supplied per-node wind; the reference's `default:` arm       */
 };
+/* Codes 2, 4 and 5 (thermal, two thermals, cyclic wind) are accepted and mean TOLFG_WIND_NONE: the bodies of those arms are
+ * commented out in the reference (src/problem.cpp:534-542,698-730), so its modelWind leaves the wind vectors as the
+ * constructor zeroed them.  Any other code is refused (TOLFG_ERR_ARG). */
 
 /* A regular ENU grid of the north wind component v, the only one the reference interpolates
  * (src/problem.cpp:628-635,682-692).  v[(i*ny + j)*nz + k] is the value at east x0+i*dx, north
@@ -285,6 +288,24 @@ int  tolfg_batch_status(tolfg_batch *b);
 /* dObj[t] = F[t][0] for t in [0,B): the per-trajectory objectives, contiguous, ready for the
  * RCCL all-gather across GPUs (a separate small kernel; tolfg_batch_eval's dObj does it for free). */
 int  tolfg_batch_objectives(tolfg_batch *b, int B, const void *dF, long ldf, void *dObj, void *stream);
+
+/* Where the outputs live.  A launch beyond the Infinity Cache streams F and G from ~2000 concurrent store fronts, and WHERE
+ * the G buffer landed in HBM decides whether they run at 4.7 or at 6 TB/s: one and the same launch takes 308 us on one 1.4 GB
+ * allocation and 281 us on the next (profiles/r04_allocation_classes.md; the vendor's fill runs at the same speed on both).  A
+ * plain hipMalloc of that size lands in the slow class most of the time; one address range backed by 2 MiB physical chunks
+ * (HIP virtual-memory management) lands in the fast one most of the time.  So the library offers:
+ *   tolfg_device_alloc / tolfg_device_free: device memory in that form (falls back to hipMalloc where the runtime has no
+ *     virtual-memory support) -- for X, F, G or anything else; a pointer from it is an ordinary device pointer;
+ *   tolfg_batch_alloc_outputs: the G buffer of B trajectories ([B][*ldg] elements of the batch dtype, *ldg = the row length
+ *     rounded up to 16 bytes), PLACED for this batch's launch: up to `tries` candidates (1..8; 3 is plenty) from
+ *     tolfg_device_alloc, each timed with the bare store loop of the launch's own shape (tolfg_batch_set_store_shape), the
+ *     fastest kept, the rest freed.  probe_us (NULL or [tries]) receives the candidates' times in us, *tried (NULL or int)
+ *     how many were timed -- 1 and no timing when the launch's outputs fit the cache, where placement does not matter.
+ *     Blocking, tens of ms: set-up time.  Free the buffer with tolfg_device_free.
+ * Buffers from anywhere else keep working; they just take the class they land in. */
+int  tolfg_device_alloc(int device, size_t bytes, void **ptr);
+int  tolfg_device_free(void *ptr);
+int  tolfg_batch_alloc_outputs(tolfg_batch *b, int B, int tries, void **dG, long *ldg, double *probe_us, int *tried);
 
 /* Measurement aid.  While enabled, every tolfg_batch_eval attaches a start and a stop HIP event to its dispatches
  * (hipExtLaunchKernelGGL): around the whole evaluation -- fg_kernel alone in the single-launch form, fg_kernel through

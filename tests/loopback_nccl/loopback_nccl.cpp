@@ -11,6 +11,7 @@
 // Semantics kept from NCCL: calls between ncclGroupStart / ncclGroupEnd are deferred to the outermost ncclGroupEnd; a
 // collective runs once every rank of its communicator set has posted its call; the result is ordered on each rank's
 // stream after the work that stream already held, and the send buffers may be reused by work queued afterwards.
+// (Unlike NCCL it blocks the host while the streams drain: see run().)
 #include <hip/hip_runtime.h>
 
 #include <cstring>
@@ -68,7 +69,14 @@ int run(World *w)
         for (int s = 0; s < n; ++s)
             if (s != r) HIP_OK(hipStreamWaitEvent(w->op[r].stream, w->before[s], 0));
     }
-    // 2. the data movement
+    // 2. the data movement.  The streams are drained on the host first: without that, a small device-to-device
+    //    hipMemcpyAsync queued right behind the evaluation kernel on the same stream was seen (2 runs in 25, ROCm 7.2.0) to
+    //    deliver 0.0 for the objective the kernel's LAST finalizing wave writes -- a stale read this test double has no
+    //    business depending on either way.  RCCL's collectives are kernels; a test double can afford to block.
+    for (int s = 0; s < n; ++s) {
+        HIP_OK(hipSetDevice(w->comm[s]->device));
+        HIP_OK(hipStreamSynchronize(w->op[s].stream));
+    }
     if (w->op[0].kind == kAllGather) {
         for (int r = 0; r < n; ++r) {
             HIP_OK(hipSetDevice(w->comm[r]->device));
@@ -79,7 +87,6 @@ int run(World *w)
         std::vector<char> acc(bytes, 0), one(bytes);
         for (int s = 0; s < n; ++s) {
             HIP_OK(hipSetDevice(w->comm[s]->device));
-            HIP_OK(hipStreamSynchronize(w->op[s].stream));
             HIP_OK(hipMemcpy(one.data(), w->op[s].send, bytes, hipMemcpyDeviceToHost));
             for (size_t i = 0; i < w->op[0].count; ++i) {
                 if (w->op[0].dtype == 8) reinterpret_cast<double *>(acc.data())[i] += reinterpret_cast<const double *>(one.data())[i];

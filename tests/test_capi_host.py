@@ -191,3 +191,18 @@ def test_mixed_batch_set_up_needs_no_gpu(tolfg, oracle):
     single = tolfg.Batch("S10", ["tempest"], ts=20)
     with pytest.raises(tolfg.TolfgError):
         single.sizes_of("G7")
+
+
+def test_wind_model_codes_the_reference_leaves_empty_are_accepted_and_others_refused(tolfg):
+    """The reference's arms 2, 4, 5 of modelWind have their bodies commented out (src/problem.cpp:534-542,698-730): the
+    problem is built and evaluates without wind; a code the reference does not know is refused."""
+    for wm in (2, 4, 5):
+        p = tolfg.Problem("S10", "tempest", ts=20, windmodel=wm)
+        assert (p.n, p.neF) == (232, 172)
+        p.close()
+        bt = tolfg.Batch("G7", ["tempest"], ts=20, windmodel=wm)
+        bt.close()
+    for wm in (6, 7, -1, 98):
+        with pytest.raises(tolfg.TolfgError) as e:
+            tolfg.Problem("S10", "tempest", ts=20, windmodel=wm)
+        assert e.value.code == tolfg.capi.ERR_ARG

@@ -53,6 +53,20 @@ def test_airframes_and_wind_models(tolfg, oracle, mission, aircraft, wind):
     p.close()
 
 
+@pytest.mark.parametrize("code", [2, 4, 5])
+def test_wind_model_codes_whose_reference_arms_are_empty_evaluate_without_wind(tolfg, oracle, code):
+    """src/problem.cpp:534-542,698-730: the thermal / two-thermal / cyclic arms are commented out, the wind vectors stay zero."""
+    p = tolfg.Problem("S10", "tempest", ts=60, windmodel=code, **_goal("S10"))
+    o = oracle.Problem("S10", "tempest", N=60, windmodel=0, **_goal("S10"))
+    x = oracle.perturbed(o, 31)
+    F, G, st = p.define_fg(x)
+    Fo, Go = o.eval(x)
+    assert st == 1
+    assert_close(F, Fo, what="F")
+    assert_close(G, Go, mask=o.undefined_mask(), what="G")
+    p.close()
+
+
 def test_need_flags_and_untouched_outputs(tolfg, oracle):
     """needF/needG = 0 must leave the corresponding array untouched (src/DefineFG.cpp:26,36)."""
     p = tolfg.Problem("S10", "tempest", ts=100, **_goal("S10"))

@@ -95,3 +95,36 @@ def test_rows_through_lds_in_two_passes_equal_one_pass(tolfg, monkeypatch, seed)
         what = (mission, N, B, dtype, pattern, off)
         assert same(outs[0][0], outs[1][0]) and same(outs[0][1], outs[1][1]), what
         assert torch_isnan(outs[1][2]).all() and torch_isnan(outs[1][3]).all(), what     # nothing written outside G
+
+
+def test_first_evaluation_on_a_non_blocking_stream_finalizes_every_trajectory(tolfg):
+    """The first evaluation of a batch object sets up its workspace (arrival counters, empty partial slots).  That set-up
+    is ordered on the LAUNCH stream: on the null stream it was not ordered against a non-blocking stream, and about one
+    first evaluation in 25 left a trajectory without its finalizing wave (objective and boundary rows unwritten) -- found by
+    tests/test_multi_loopback.py, whose parts launch on such streams.  Many fresh batch objects, each evaluated once."""
+    import torch
+    trajs = [tolfg.Trajectory(aircraft=t % 2, mission=("S10", "G7")[t % 2], radius_goal=100.0 * (1 - t % 2), Vref=1.0 + t) for t in range(6)]
+    stream = torch.cuda.Stream()          # non-blocking with respect to the null stream
+    src = tolfg.Batch("mixed", ["tempest", "skywalker"], ts=200)
+    src.set_trajectories(trajs)
+    dX, dF, dG = src.alloc(6)
+    src.x0_device(dX)
+    torch.cuda.synchronize()
+    ref = None
+    for trial in range(80):
+        bt = tolfg.Batch("mixed", ["tempest", "skywalker"], ts=200)
+        bt.set_trajectories(trajs)
+        obj = torch.full((6,), float("nan"), dtype=torch.float64, device="cuda")
+        dF.fill_(float("nan"))
+        torch.cuda.synchronize()
+        with torch.cuda.stream(stream):
+            bt.eval(dX, dF, dG, obj=obj)
+        stream.synchronize()
+        got = (obj.clone(), dF[:, 0].clone(), dF[:, 1601:1612].clone())
+        assert torch.isfinite(got[0]).all() and torch.isfinite(got[1]).all() and torch.isfinite(got[2]).all(), (trial, got[0])
+        if ref is None:
+            ref = got
+        assert all(torch.equal(a, b) for a, b in zip(got, ref)), trial
+        bt.status()
+        bt.close()
+    src.close()

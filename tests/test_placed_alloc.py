@@ -1,0 +1,85 @@
+"""The library's device allocator (include/tolfg.h "Where the outputs live"): one address range backed by 2 MiB physical
+chunks, and the placement-probing allocation of a batch's G buffer."""
+import ctypes as C
+import gc
+
+import numpy as np
+import pytest
+
+from helpers import assert_close
+
+
+def test_entry_points_refuse_bad_arguments_without_a_gpu(tolfg):
+    L = tolfg.lib()
+    assert L.tolfg_device_alloc(0, 1 << 20, None) == tolfg.capi.ERR_ARG
+    assert L.tolfg_device_free(None) == 0                                   # freeing nothing is fine
+    assert L.tolfg_device_free(C.c_void_p(0x1000)) == tolfg.capi.ERR_ARG    # not one of ours
+    ptr, ldg = C.c_void_p(), C.c_long()
+    assert L.tolfg_batch_alloc_outputs(None, 4, 3, C.byref(ptr), C.byref(ldg), None, None) == tolfg.capi.ERR_ARG
+    bt = tolfg.Batch("S10", ["tempest"], ts=20)
+    bt.set_trajectories([tolfg.Trajectory() for _ in range(4)])
+    assert L.tolfg_batch_alloc_outputs(bt._h, 9, 3, C.byref(ptr), C.byref(ldg), None, None) == tolfg.capi.ERR_ARG   # more rows than described
+    bt.close()
+
+
+@pytest.mark.gpu
+def test_placed_memory_is_ordinary_device_memory_and_is_freed_with_its_tensor(tolfg):
+    import torch
+    L = tolfg.lib()
+    t = tolfg.device_alloc((3, 1000), "f64")
+    ptr = t.data_ptr()
+    assert ptr % (2 << 20) == 0 and t.shape == (3, 1000) and t.dtype == torch.float64 and t.is_cuda
+    t.fill_(2.5)
+    t[1, :10] = torch.arange(10, dtype=torch.float64, device="cuda")
+    assert float(t.sum()) == 2.5 * 2990 + 45.0
+    u = t[1:]                                   # a view keeps the block alive
+    del t
+    gc.collect()
+    assert float(u[0, 3]) == 3.0
+    del u
+    gc.collect()
+    torch.cuda.synchronize()
+    assert L.tolfg_device_free(C.c_void_p(ptr)) == tolfg.capi.ERR_ARG       # already freed by the owner: unknown now
+    # several blocks, sizes that are not chunk multiples, both dtypes
+    blocks = [tolfg.device_alloc((n,), dt) for n, dt in ((1, "f32"), (262145, "f64"), (5 << 20, "f32"))]
+    for i, b in enumerate(blocks):
+        b.fill_(float(i + 1))
+    torch.cuda.synchronize()
+    assert [float(b[-1]) for b in blocks] == [1.0, 2.0, 3.0]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mission,dtype,B,N", [("S10", "f64", 1600, 200), ("mixed", "f32", 3000, 200), ("G7", "f64", 40, 200)])
+def test_outputs_in_a_placed_buffer_match_the_oracle(tolfg, oracle, mission, dtype, B, N):
+    """tolfg_batch_alloc_outputs: launches beyond the cache time their candidates (probe times reported, the kept buffer is the
+    fastest), launches within it take one; the evaluation into the buffer is the evaluation."""
+    import torch
+    air = ["tempest", "skywalker"]
+    ms = [("S10", "G7")[t % 2] if mission == "mixed" else mission for t in range(B)]
+    trajs = [tolfg.Trajectory(aircraft=t % 2, mission=ms[t], radius_goal=100.0 if ms[t] == "S10" else 0.0, Vref=0.5 + 0.001 * t, href=9.0,
+                              xi=float(t % 13), yi=-float(t % 7), zi=-40.0 - (t % 5)) for t in range(B)]
+    bt = tolfg.Batch(mission, air, ts=N, dtype=dtype)
+    bt.set_trajectories(trajs)
+    dX, dF, dG = bt.alloc(B)                      # placed by default
+    beyond = bt.algorithmic_bytes(B) > 300e6
+    assert bt.placement["candidates"] == (3 if beyond else 1)
+    if beyond:
+        pr = bt.placement["probe_us"]
+        assert len(pr) == 3 and all(p > 0 for p in pr)
+    assert dG.shape[0] == B and dG.shape[1] >= bt.neG and dG.data_ptr() % (2 << 20) == 0
+    bt.x0_device(dX)
+    bt.eval(dX, dF, dG)
+    torch.cuda.synchronize()
+    plain = torch.zeros_like(dG)                  # torch's own allocation: the same numbers
+    F2 = torch.zeros_like(dF)
+    bt.eval(dX, F2, plain)
+    torch.cuda.synchronize()
+    assert torch.equal(dG[:, :bt.neG], plain[:, :bt.neG]) and torch.equal(dF[:, :bt.neF], F2[:, :bt.neF])
+    if dtype == "f64":
+        for t in (0, B - 1):
+            tr = trajs[t]
+            o = oracle.Problem(tr.mission, air[tr.aircraft], N=N, radius_goal=tr.radius_goal, Vref=tr.Vref, href=tr.href, start=(tr.xi, tr.yi, tr.zi))
+            Fo, Go = o.eval(dX[t, :o.n].cpu().numpy())
+            assert_close(dF[t, :len(Fo)].cpu().numpy(), Fo, what=f"F[{t}]")
+            assert_close(dG[t, :len(Go)].cpu().numpy(), Go, mask=o.undefined_mask(), what=f"G[{t}]")
+    bt.close()

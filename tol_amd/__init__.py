@@ -7,6 +7,6 @@ evaluation needs a gfx950 device and raises TolfgError otherwise.
 """
 from .capi import TolfgError, lib, lib_path   # noqa: F401
 from . import capi                             # noqa: F401
-from .host import Batch, Multi, Problem, Trajectory  # noqa: F401
+from .host import Batch, Multi, Problem, Trajectory, device_alloc  # noqa: F401
 
 __all__ = ["Batch", "Multi", "Problem", "Trajectory", "TolfgError", "capi", "lib", "lib_path"]

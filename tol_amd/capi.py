@@ -108,6 +108,9 @@ SYMBOLS = {
     "tolfg_batch_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "tolfg_batch_kernel_time": (C.c_int, [C.c_void_p, _dp, _dp]),
     "tolfg_batch_set_store_shape": (C.c_int, [C.c_void_p, C.c_int]),
+    "tolfg_device_alloc": (C.c_int, [C.c_int, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "tolfg_device_free": (C.c_int, [C.c_void_p]),
+    "tolfg_batch_alloc_outputs": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_long), _dp, _ip]),
     "tolfg_batch_algorithmic_bytes": (C.c_double, [C.c_void_p, C.c_int]),
     "tolfg_multi_create": (C.c_int, [C.POINTER(BatchConfig), _ip, C.c_int, C.POINTER(C.c_void_p)]),
     "tolfg_multi_destroy": (None, [C.c_void_p]),

@@ -442,6 +442,25 @@ int tolfg_batch_set_timing(tolfg_batch *h, int enable)
     return guarded([&] { h->b->set_timing(enable != 0); });
 }
 
+int tolfg_device_alloc(int device, size_t bytes, void **ptr)
+{
+    if (!ptr) return fail(TOLFG_ERR_ARG, "tolfg_device_alloc: null argument");
+    *ptr = nullptr;
+    return guarded([&] { *ptr = device_alloc(device, bytes); });
+}
+
+int tolfg_device_free(void *ptr)
+{
+    return guarded([&] { device_free(ptr); });
+}
+
+int tolfg_batch_alloc_outputs(tolfg_batch *h, int B, int tries, void **dG, long *ldg, double *probe_us, int *tried)
+{
+    if (!h || !dG) return fail(TOLFG_ERR_ARG, "tolfg_batch_alloc_outputs: null argument");
+    *dG = nullptr;
+    return guarded([&] { *dG = h->b->alloc_outputs(B, tries, ldg, probe_us, tried); });
+}
+
 int tolfg_batch_set_store_shape(tolfg_batch *h, int enable)
 {
     if (!h) return fail(TOLFG_ERR_ARG, "null batch");

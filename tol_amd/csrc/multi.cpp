@@ -206,9 +206,13 @@ void multi::free_buffers()
     hAll_ = nullptr;
     for (Part &p : part_) {
         (void)hipSetDevice(p.device);
-        for (void **q : {&p.dX, &p.dF, &p.dG, &p.dObj, &p.dAll, &p.dWind}) {
+        for (void **q : {&p.dX, &p.dF, &p.dObj, &p.dAll, &p.dWind}) {
             if (*q) (void)hipFree(*q);
             *q = nullptr;
+        }
+        if (p.dG) {
+            try { device_free(p.dG); } catch (const std::exception &) {}
+            p.dG = nullptr;
         }
     }
 }
@@ -294,7 +298,14 @@ void multi::set_trajectories(long total, const tolfg_traj *trajs)
         const size_t rows = (size_t)(B > 0 ? B : 1);
         check(hipMalloc(&p.dX, elem() * rows * ldx_), "hipMalloc(X)");
         check(hipMalloc(&p.dF, elem() * rows * ldf_), "hipMalloc(F)");
-        check(hipMalloc(&p.dG, elem() * rows * ldg_), "hipMalloc(G)");
+        // G, the bulk of what a launch writes, comes placed for this shard's launch (problem.h: alloc_outputs)
+        if (B > 0) {
+            long ldg = 0;
+            p.dG = p.b->alloc_outputs((int)B, 3, &ldg, nullptr, nullptr);
+            if (ldg != ldg_) throw std::logic_error("tolfg_multi: row stride of the placed G buffer");
+        } else {
+            p.dG = device_alloc(p.device, elem() * rows * ldg_);
+        }
         check(hipMalloc(&p.dObj, elem() * (size_t)width_), "hipMalloc(obj)");
         check(hipMalloc(&p.dAll, elem() * (size_t)width_ * world), "hipMalloc(gathered)");
         check(hipMemsetAsync(p.dObj, 0, elem() * (size_t)width_, p.stream), "hipMemsetAsync(obj)");

@@ -9,6 +9,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 
 #include <hip/hip_runtime_api.h>
 
@@ -40,6 +42,9 @@ int kernel_wind(int windmodel)
     case TOLFG_WIND_SHEAR: return WIND_SHEAR;
     case TOLFG_WIND_TABLE: return WIND_TABLE;
     case TOLFG_WIND_GRID:  return WIND_GRID;
+    // the reference's thermal (2), two-thermal (4) and cyclic (5) arms have their bodies commented out (src/problem.cpp:534-542,
+    // 698-730): modelWind leaves the wind vectors as the constructor zeroed them, i.e. no wind
+    case 2: case 4: case 5: return WIND_NONE;
     }
     throw std::invalid_argument("unknown wind model");
 }
@@ -70,6 +75,102 @@ std::string default_root()
     return "./";   // the reference's command-line root_path (src/arguments.cpp:45)
 }
 
+// ------------------------------------------------------------------------------------ placed device memory
+
+namespace {
+// the calling thread's current device is the caller's business
+struct DeviceGuardLocal {
+    int prev = -1;
+    DeviceGuardLocal() { if (hipGetDevice(&prev) != hipSuccess) prev = -1; }
+    ~DeviceGuardLocal() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+struct DeviceBlock {
+    int device = 0;
+    size_t bytes = 0, chunk = 0;                           // chunk = 0: a plain hipMalloc (no virtual-memory support)
+    std::vector<hipMemGenericAllocationHandle_t> handles;
+};
+std::mutex g_blocks_mu;
+std::map<void *, DeviceBlock> g_blocks;
+constexpr size_t kPlacedChunk = 2u << 20;
+
+void release_block(void *ptr, DeviceBlock &b)
+{
+    (void)hipSetDevice(b.device);
+    if (b.chunk == 0) { (void)hipFree(ptr); return; }
+    (void)hipMemUnmap(ptr, b.bytes);
+    for (hipMemGenericAllocationHandle_t h : b.handles) (void)hipMemRelease(h);
+    (void)hipMemAddressFree(ptr, b.bytes);
+}
+}  // namespace
+
+void *device_alloc(int device, size_t bytes)
+{
+    if (bytes == 0) throw std::invalid_argument("device_alloc: zero bytes");
+    check(hipSetDevice(device), "hipSetDevice");
+    DeviceBlock blk;
+    blk.device = device;
+    void *ptr = nullptr;
+    hipMemAllocationProp prop{};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = device;
+    size_t gran = 0;
+    bool vmm = hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) == hipSuccess && gran > 0 &&
+               kPlacedChunk % gran == 0;
+    if (vmm) {
+        blk.chunk = kPlacedChunk;
+        blk.bytes = (bytes + kPlacedChunk - 1) / kPlacedChunk * kPlacedChunk;
+        if (hipMemAddressReserve(&ptr, blk.bytes, kPlacedChunk, nullptr, 0) != hipSuccess || !ptr) { vmm = false; ptr = nullptr; }
+    }
+    if (vmm) {
+        bool ok = true;
+        size_t mapped = 0;
+        for (size_t off = 0; off < blk.bytes && ok; off += kPlacedChunk) {
+            hipMemGenericAllocationHandle_t h{};
+            ok = hipMemCreate(&h, kPlacedChunk, &prop, 0) == hipSuccess;
+            if (!ok) break;
+            blk.handles.push_back(h);
+            ok = hipMemMap(static_cast<char *>(ptr) + off, kPlacedChunk, 0, h, 0) == hipSuccess;
+            if (ok) mapped = off + kPlacedChunk;
+        }
+        hipMemAccessDesc acc{};
+        acc.location = prop.location;
+        acc.flags = hipMemAccessFlagsProtReadWrite;
+        if (ok) ok = hipMemSetAccess(ptr, blk.bytes, &acc, 1) == hipSuccess;
+        if (!ok) {             // out of memory or an unsupported step: undo, report
+            if (mapped) (void)hipMemUnmap(ptr, mapped);
+            for (hipMemGenericAllocationHandle_t h : blk.handles) (void)hipMemRelease(h);
+            (void)hipMemAddressFree(ptr, blk.bytes);
+            clear_errors();
+            throw hip_failure("device_alloc: the virtual-memory allocation of " + std::to_string(bytes) + " bytes failed");
+        }
+    } else {
+        clear_errors();
+        blk = DeviceBlock{};
+        blk.device = device;
+        blk.bytes = bytes;
+        check(hipMalloc(&ptr, bytes), "hipMalloc");
+    }
+    std::lock_guard<std::mutex> lk(g_blocks_mu);
+    g_blocks[ptr] = std::move(blk);
+    return ptr;
+}
+
+void device_free(void *ptr)
+{
+    if (!ptr) return;
+    DeviceBlock blk;
+    {
+        std::lock_guard<std::mutex> lk(g_blocks_mu);
+        auto it = g_blocks.find(ptr);
+        if (it == g_blocks.end()) throw std::invalid_argument("device_free: not a pointer tolfg_device_alloc returned");
+        blk = std::move(it->second);
+        g_blocks.erase(it);
+    }
+    DeviceGuardLocal guard;
+    release_block(ptr, blk);
+}
+
 // ------------------------------------------------------------------------------------ batch
 
 batch::batch(const std::string &mission, const std::string &root, const std::vector<std::string> &names,
@@ -80,6 +181,7 @@ batch::batch(const std::string &mission, const std::string &root, const std::vec
     if (names.empty() || names.size() > MAX_AIRCRAFT) throw std::invalid_argument("1..8 aircraft per batch");
     if (dtype != TOLFG_F64 && dtype != TOLFG_F32) throw std::invalid_argument("dtype");
     kernel_wind(windmodel);
+    if (windmodel == 2 || windmodel == 4 || windmodel == 5) windmodel_ = TOLFG_WIND_NONE;
     for (const std::string &nm : names) acs_.emplace_back(nm, root);
     const char *mname[2] = {"S10", "G7"};
     for (int m = 0; m < 2; ++m) {
@@ -283,8 +385,8 @@ void batch::eval(int B, const void *dX, long ldx, void *dF, long ldf, void *dG, 
     if (!dX || (needF && !dF) || (needG && !dG)) throw std::invalid_argument("eval: null device pointer");
     if (ldx < sz_.n || (needF && ldf < sz_.neF) || (needG && ldg < sz_.neG))
         throw std::invalid_argument("eval: leading dimension smaller than the row");
-    if (windmodel_ == TOLFG_WIND_TABLE && !dWind) throw std::invalid_argument("eval: table wind needs dWind");
-    if (windmodel_ == TOLFG_WIND_GRID && !d_grid_) throw std::invalid_argument("eval: grid wind needs tolfg_*_set_wind_grid");
+    if (windmodel_ == TOLFG_WIND_TABLE && !dWind && !store_shape_) throw std::invalid_argument("eval: table wind needs dWind");
+    if (windmodel_ == TOLFG_WIND_GRID && !d_grid_ && !store_shape_) throw std::invalid_argument("eval: grid wind needs tolfg_*_set_wind_grid");
     if (!uploaded_) upload();
     // Stream contract (include/tolfg.h): the per-launch workspace (objective partials, arrival counters) belongs to ONE
     // evaluation at a time.  Evaluations on one stream are ordered by the stream; a caller that moves to another stream
@@ -333,8 +435,11 @@ void batch::eval(int B, const void *dX, long ldx, void *dF, long ldf, void *dG, 
         if (d_partial_) check(hipFree(d_partial_), "hipFree");
         d_partial_ = nullptr;
         check(hipMalloc(reinterpret_cast<void **>(&d_partial_), sizeof(double) * 2 * (size_t)W), "hipMalloc(partial)");
-        // fused path: every slot starts empty and is emptied again by the wave that read it
-        check(hipMemsetD32(reinterpret_cast<hipDeviceptr_t>(d_partial_), kEmptySlotWord, 4 * (size_t)W), "hipMemsetD32(partial)");
+        // fused path: every slot starts empty and is emptied again by the wave that read it.  ON THE LAUNCH STREAM: a memset on
+        // the null stream is not ordered against a non-blocking stream, and a launch that overtook it found its arrival
+        // counters zeroed under its feet -- one trajectory in a few thousand first evaluations went without its finalizing
+        // wave (objective and boundary rows not written; caught by tests/test_multi_loopback.py, whose parts use such streams)
+        check(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(d_partial_), kEmptySlotWord, 4 * (size_t)W, stream), "hipMemsetD32Async(partial)");
         partial_cap_ = W;
         partial_dirty_ = false;
     }
@@ -343,7 +448,7 @@ void batch::eval(int B, const void *dX, long ldx, void *dF, long ldf, void *dG, 
         if (d_counter_) check(hipFree(d_counter_), "hipFree");
         d_counter_ = nullptr;
         check(hipMalloc(reinterpret_cast<void **>(&d_counter_), sizeof(unsigned) * ((size_t)B + 1)), "hipMalloc(counter)");
-        check(hipMemset(d_counter_, 0, sizeof(unsigned) * ((size_t)B + 1)), "hipMemset(counter)");
+        check(hipMemsetAsync(d_counter_, 0, sizeof(unsigned) * ((size_t)B + 1), stream), "hipMemsetAsync(counter)");
         counter_cap_ = B;
     }
     a.partial = d_partial_;
@@ -454,6 +559,80 @@ void batch::objectives(int B, const void *dF, long ldf, void *dObj, hipStream_t 
 {
     if (!dF || !dObj || B < 1) throw std::invalid_argument("objectives: bad arguments");
     check(launch_objectives(dF, ldf, dObj, B, dtype_, stream), "launch objectives");
+}
+
+void *batch::alloc_outputs(int B, int tries, long *ldg_out, double *probe_us, int *tried)
+{
+    if (B < 1 || B > ntraj_) throw std::invalid_argument("alloc_outputs: B exceeds the described trajectories");
+    const long v = dtype_ == TOLFG_F64 ? 2 : 4;
+    const long ldg = (sz_.neG + v - 1) / v * v;
+    const size_t bytes = elem_size() * (size_t)B * (size_t)ldg;
+    if (ldg_out) *ldg_out = ldg;
+    const double out_bytes = (double)elem_size() * B * ((double)sz_.neF + sz_.neG);
+    const LaunchPlan lp = plan_launch(LaunchShape{B, sz_.N, dtype_, args_.pattern, mission_, 1, out_bytes});
+    // placement matters to launches that stream beyond the cache (non-temporal form); the others take what they get
+    const int n = (tries < 1 || !lp.nt_stores || lp.single) ? 1 : (tries > 8 ? 8 : tries);
+    if (probe_us) for (int i = 0; i < (tries > 0 ? tries : 1); ++i) probe_us[i] = 0.0;
+    if (tried) *tried = n;
+    if (n == 1) return device_alloc(device_, bytes);
+    check(hipSetDevice(device_), "hipSetDevice");
+    hipStream_t stream = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    check(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking), "hipStreamCreate");
+    void *best = nullptr;
+    double best_us = 0.0;
+    const bool was_store_shape = store_shape_;
+    const hipStream_t prev_stream = last_stream_;
+    const bool had_prev = have_last_stream_;
+    try {
+        check(hipEventCreate(&e0), "hipEventCreate");
+        check(hipEventCreate(&e1), "hipEventCreate");
+        store_shape_ = true;
+        for (int i = 0; i < n; ++i) {
+            void *cand = device_alloc(device_, bytes);
+            double us = 0.0;
+            try {
+                // the bare store loop reads nothing but the trajectory table: G itself stands in for X
+                auto run = [&](int reps) {
+                    for (int r = 0; r < reps; ++r) eval(B, cand, ldg, nullptr, 0, cand, ldg, nullptr, 0, 1, stream);
+                };
+                run(3);
+                check(hipEventRecord(e0, stream), "hipEventRecord");
+                run(10);
+                check(hipEventRecord(e1, stream), "hipEventRecord");
+                check(hipEventSynchronize(e1), "hipEventSynchronize");
+                float ms = 0;
+                check(hipEventElapsedTime(&ms, e0, e1), "hipEventElapsedTime");
+                us = 1e3 * ms / 10;
+            } catch (...) {
+                device_free(cand);
+                throw;
+            }
+            if (probe_us) probe_us[i] = us;
+            if (!best || us < best_us) {
+                if (best) device_free(best);
+                best = cand;
+                best_us = us;
+            } else {
+                device_free(cand);
+            }
+        }
+    } catch (...) {
+        store_shape_ = was_store_shape;
+        if (best) device_free(best);
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+        (void)hipStreamDestroy(stream);
+        throw;
+    }
+    store_shape_ = was_store_shape;
+    check(hipStreamSynchronize(stream), "hipStreamSynchronize");
+    last_stream_ = prev_stream;            // the probe's private stream is gone: the stream contract resumes where it was
+    have_last_stream_ = had_prev;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipStreamDestroy(stream);
+    return best;
 }
 
 // ------------------------------------------------------------------------------------ problem

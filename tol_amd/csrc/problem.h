@@ -24,6 +24,14 @@ struct hip_failure : std::runtime_error {
 int mission_from_name(const std::string &name, bool allow_mixed = false);
 std::string default_root();
 
+// Device memory as ONE address range backed by 2 MiB physical chunks (HIP virtual-memory management: hipMemAddressReserve,
+// hipMemCreate + hipMemMap per chunk).  Why: where a launch's output buffer lands in HBM decides whether the kernel's ~2000
+// concurrent store fronts run at 4.7 or at 6 TB/s (profiles/r04_allocation_classes.md) -- a plain hipMalloc of 1.4 GB lands in
+// the slow class most of the time, this form in the fast one most of the time, and batch::alloc_outputs times candidates and
+// keeps the best.  Falls back to hipMalloc where the runtime has no virtual-memory support.  Thread-safe registry.
+void *device_alloc(int device, size_t bytes);
+void device_free(void *ptr);           // no-op for nullptr; throws for a pointer device_alloc did not return
+
 // ---------------------------------------------------------------------------------------------
 // Device-resident evaluation of B independent trajectories that share ts; mission "S10", "G7" or
 // "mixed" (every trajectory names its own mission; rows are sized for the larger one).
@@ -74,6 +82,12 @@ public:
     void objectives(int B, const void *dF, long ldf, void *dObj, hipStream_t stream);
     void x0_device(int B, void *dX, long ldx, hipStream_t stream);
     void bounds_device(int B, void *dXlow, void *dXupp, long ldx, void *dFlow, void *dFupp, long ldf, hipStream_t stream);
+    // The G buffer of B trajectories ([B][ldg] elements, ldg = the row length rounded up to 16 bytes), placed for this
+    // batch's launch: up to `tries` candidates from device_alloc, each timed with the bare store loop of the launch's own
+    // shape (store_shape_kernel), the fastest kept, the rest freed.  Launches whose outputs fit the Infinity Cache do not
+    // depend on placement: one candidate, not timed.  probe_us (optional, [tries]): the times, 0 where not timed.  The
+    // caller frees the buffer with device_free.  Blocking (set-up time: tens of ms).
+    void *alloc_outputs(int B, int tries, long *ldg, double *probe_us, int *tried);
     // measurement aid: HIP events recorded on the launch stream around fg_kernel of every eval
     void set_timing(bool on);
     int kernel_time(double *avg_ms, double *min_ms);   // launches averaged since the last call

@@ -41,6 +41,38 @@ def _wind_grid(v, origin, spacing, datum):
     return g, v
 
 
+class _DeviceBlock:
+    """Owner of a tolfg_device_alloc block, seen by torch through __cuda_array_interface__; freed with the last tensor."""
+
+    def __init__(self, ptr, shape, typestr):
+        self.ptr = ptr
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (ptr, False), "version": 2}
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                lib().tolfg_device_free(C.c_void_p(self.ptr))
+                self.ptr = None
+        except Exception:
+            pass
+
+
+def _owned_tensor(ptr, shape, dtype, device):
+    import torch
+    blk = _DeviceBlock(ptr, shape, "<f8" if dtype == "f64" else "<f4")
+    return torch.as_tensor(blk, device=torch.device("cuda", device))
+
+
+def device_alloc(shape, dtype="f64", device=0):
+    """A device tensor [shape] in the library's placed form (tolfg_device_alloc); the tensor owns the memory."""
+    n = 1
+    for d in shape:
+        n *= int(d)
+    ptr = C.c_void_p()
+    check(lib().tolfg_device_alloc(int(device), n * (8 if dtype == "f64" else 4), C.byref(ptr)))
+    return _owned_tensor(ptr.value, tuple(int(d) for d in shape), dtype, device)
+
+
 class Problem:
     """ref: `new problemS10(args)` / `new problemG7(args)` + what runSNOPT hands to SNOPT."""
 
@@ -306,8 +338,12 @@ class Batch:
         import torch
         return torch.float64 if self.dtype == "f64" else torch.float32
 
-    def alloc(self, B=None, pad=None):
-        """X, F, G device tensors with row strides padded to `pad` elements (default: 16 bytes)."""
+    def alloc(self, B=None, pad=None, placed=None, tries=3):
+        """X, F, G device tensors with row strides padded to `pad` elements (default: 16 bytes).
+        placed (default: True when the trajectories are described and pad is the default): G comes from the library's
+        placement-probing allocator (tolfg_batch_alloc_outputs: an address range backed by 2 MiB physical chunks, the best
+        of up to `tries` candidates by the bare store loop of this batch's launch -- where G lands in HBM decides the class
+        the launch runs in, include/tolfg.h); the probe times are kept in self.placement.  The tensor owns the memory."""
         import torch
         B = self.B if B is None else B
         v = pad if pad is not None else (2 if self.dtype == "f64" else 4)
@@ -316,8 +352,25 @@ class Batch:
         dt = self.torch_dtype()
         X = torch.zeros((B, up(self.n)), dtype=dt, device=dev)
         F = torch.zeros((B, up(self.neF)), dtype=dt, device=dev)
-        G = torch.zeros((B, up(self.neG)), dtype=dt, device=dev)
+        if placed is None:
+            placed = pad is None and 0 < B <= getattr(self, "B", 0)
+        if placed:
+            G = self.alloc_outputs(B, tries)
+            G.zero_()
+        else:
+            G = torch.zeros((B, up(self.neG)), dtype=dt, device=dev)
         return X, F, G
+
+    def alloc_outputs(self, B, tries=3):
+        """The G tensor [B][ldg] from tolfg_batch_alloc_outputs (uninitialised); self.placement records the probe."""
+        import torch
+        ptr, ldg, tried = C.c_void_p(), C.c_long(), C.c_int()
+        probe = (C.c_double * max(int(tries), 1))()
+        check(lib().tolfg_batch_alloc_outputs(self._h, int(B), int(tries), C.byref(ptr), C.byref(ldg), probe, C.byref(tried)))
+        self.placement = {"allocator": "tolfg_batch_alloc_outputs: one address range backed by 2 MiB physical chunks; best of the "
+                                       "candidates by the bare store loop of the launch's own shape",
+                          "candidates": tried.value, "probe_us": [round(probe[i], 2) for i in range(tried.value)] if tried.value > 1 else []}
+        return _owned_tensor(ptr.value, (int(B), ldg.value), self.dtype, self.device)
 
     def _check(self, t, name, rows, cols):
         """The C ABI takes raw pointers and strides: a tensor of the wrong dtype, device or layout would

@@ -65,7 +65,7 @@ def main():
     md.append(f"# rocprofv3 summary `{tag}` -- bench.py, {mission}/ts={ts}/{dtype}, batch {batch} per GPU, 1 MI355X\n")
     extra = "" if dtype == "f64" and mission == "mixed" else f" --dtype {dtype} --mission {mission} --batch {batch}"
     md.append("Command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --steps 50 --warmup 5 "
-              f"--no-cpu-baseline --no-configs{extra}` (tools/profile_gpu.sh); counters from two further passes of the same "
+              f"--no-cpu-baseline --no-configs --no-calibration{extra}` (tools/profile_gpu.sh); counters from two further passes of the same "
               "command with `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE`.\n")
     md.append("## Kernel time (`--stats`)\n")
     md.append("| kernel | calls | avg us | min us | max us | % |\n|---|---|---|---|---|---|")

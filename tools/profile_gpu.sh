@@ -4,16 +4,16 @@
 # Counters are collected in their own passes (kernel-trace only, no other trace domains).
 set -e
 TAG=${1:-r01}
-ARGS=${2:-"--steps 50 --warmup 5 --no-cpu-baseline --no-configs"}
+ARGS=${2:-"--steps 50 --warmup 5 --no-cpu-baseline --no-configs --no-calibration"}
 OUT=$PWD/gpurun_out/prof_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
 export TMPDIR=/tmp
 echo "[profile] kernel trace + stats"
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o stats -- python3 bench.py $ARGS > "$OUT/bench_stats.log" 2>&1
+timeout -k 5 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o stats -- python3 bench.py $ARGS > "$OUT/bench_stats.log" 2>&1
 echo "[profile] pmc FETCH_SIZE"
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -o fetch -- python3 bench.py $ARGS > "$OUT/bench_fetch.log" 2>&1
+timeout -k 5 240 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -o fetch -- python3 bench.py $ARGS > "$OUT/bench_fetch.log" 2>&1
 echo "[profile] pmc WRITE_SIZE"
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -o write -- python3 bench.py $ARGS > "$OUT/bench_write.log" 2>&1
+timeout -k 5 240 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -o write -- python3 bench.py $ARGS > "$OUT/bench_write.log" 2>&1
 find "$OUT" -name "*.csv" | head -50
 # keep the merged payload small: kernel-trace CSVs of the bench are a few hundred rows
 du -sh "$OUT"

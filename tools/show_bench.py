@@ -6,19 +6,23 @@ import sys
 txt = open(sys.argv[1]).read() if len(sys.argv) > 1 else sys.stdin.read()
 d = json.loads(txt.strip().splitlines()[-1])
 r = d["roofline"]
+nan = float("nan")
 print("value %.4g %s on %d GPU(s), %s scaling, backend %s; ms/step %.4f; per launch %.4f ms -> %.0f GB/s = %.3f of peak  (instrumented pass: %.4f ms, min %.4f)"
       % (d["value"], d["unit"], d["n_gpus"], d["scaling"], d.get("backend"), d["ms_per_step"], r["kernel_ms"], r["achieved"], r["frac"],
-         r.get("instrumented_kernel_ms", float("nan")), r.get("instrumented_kernel_min_ms", r.get("kernel_min_ms", float("nan")))))
+         r.get("instrumented_kernel_ms", nan), r.get("instrumented_kernel_min_ms", r.get("kernel_min_ms", nan))))
+if "box_fill_GBs" in r:
+    print("  this box, same process: vendor fill %.0f GB/s (the launch = %.3f of it); bare store loop of the launch's shape %.1f us = %.0f GB/s over its slab bytes; warm-up %s steps"
+          % (r["box_fill_GBs"] or nan, r.get("frac_of_box_fill") or nan, r.get("box_stream_shape_us") or nan, r.get("box_stream_shape_GBs") or nan, d.get("warmup_steps_run")))
 for c in d.get("configs", []):
     if c["mode"] == "callback":
-        print("  config %d callback: %.1f us/call native (%.1f via ctypes; F only %.1f) = %.3g node-evals/s  [%s]"
-              % (c["config"], c["us_per_call"], c["us_per_call_via_python_ctypes"], c.get("us_per_call_needF_only", float("nan")), c["node_evals_per_s"], c["workload"]))
+        print("  config %d callback: %.1f us/call native, arrays in place (staged: %.1f; via ctypes %.1f; F only %.1f) = %.3g node-evals/s  [%s]"
+              % (c["config"], c["us_per_call"], c.get("us_per_call_staged", nan), c["us_per_call_via_python_ctypes"], c.get("us_per_call_needF_only", nan), c["node_evals_per_s"], c["workload"]))
     else:
         extra = "" if c.get("n_gpus", 1) == 1 else " (%d per GPU x %d GPUs, gather %.1f us)" % (c["batch_per_gpu"], c["n_gpus"], c["gather_us"])
-        print("  config %d B=%d%s %s: step %.1f us, per launch %.1f us (instrumented %.1f, min %.1f) = %.0f GB/s = %.3f of peak, %.3g node-evals/s  [%s]"
-              % (c["config"], c["batch"], extra, c["dtype"], 1e3 * c["ms_per_step"], c["eval_us"], c.get("eval_us_instrumented", float("nan")),
-                 c.get("eval_min_us_instrumented", c.get("eval_min_us", float("nan"))), c["achieved_GBs"], c["frac_of_hbm_peak"],
-                 c["node_evals_per_s"], c["workload"]))
+        print("  config %d B=%d%s %s: step %.1f us, per launch %.1f us (instrumented %.1f, min %.1f) = %.0f GB/s = %.3f of peak (%.3f of this box's fill; its bare store loop %.1f us), %.3g node-evals/s  [%s]"
+              % (c["config"], c["batch"], extra, c["dtype"], 1e3 * c["ms_per_step"], c["eval_us"], c.get("eval_us_instrumented", nan),
+                 c.get("eval_min_us_instrumented", c.get("eval_min_us", nan)), c["achieved_GBs"], c["frac_of_hbm_peak"],
+                 c.get("frac_of_box_fill") or nan, c.get("box_stream_shape_us") or nan, c["node_evals_per_s"], c["workload"]))
 if "cpu_baseline" in d:
     b = d["cpu_baseline"]
     print("  cpu baseline (%s, %d core): %.4g %s; -O0 %.4g; fused 1 core %.4g; fused %d cores %.4g"
