@@ -124,6 +124,7 @@ struct LaunchShape {
     int mission;           // MISSION_*
     int aligned;           // rows of X and F on 16-byte boundaries (16-byte window loads / defect stores possible)
     double out_bytes;      // F + G bytes this launch writes
+    int needG = 1;         // the Jacobian is wanted (0: F alone)
 };
 LaunchPlan plan_launch(const LaunchShape &shape);
 

@@ -67,7 +67,9 @@ LaunchPlan plan_launch(const LaunchShape &sh)
     // a few short trajectories: one workgroup per trajectory, one launch (fg_single_kernel) -- except the callback's single
     // trajectory of 100+ nodes, which is quicker as 5 tiles on 5 CUs
     p.single = (sh.B <= 8 && sh.N <= 256 && sh.mission != MISSION_MIXED) ? 1 : 0;
-    if (p.single && sh.B == 1 && sh.N >= 100) {
+    // (with the Jacobian wanted: a call for F alone -- snOptA's line searches -- stores 13 KB and is quicker as one workgroup:
+    // 12.0-13.6 against 14.1-14.6 us at ts = 200)
+    if (p.single && sh.B == 1 && sh.N >= 100 && sh.needG) {
         p.single = 0;
         const int t = (sh.N + 27) / 28 > 5 ? (sh.N + 27) / 28 : 5;      // tiles of <= 28 nodes, at least 5 of them
         p.max_nt = ((sh.N + t - 1) / t + 3) & ~3;
@@ -77,7 +79,10 @@ LaunchPlan plan_launch(const LaunchShape &sh)
     p.nt_stores = beyond_cache ? 1 : 0;
     // fp32 compact slabs (184 bytes per node) are the one shape that wants every wave it can get beyond the cache
     // too: cap 12 / none -> 55.1 / 50.7 us at B=4096, 112.0 / 106.0 us for the mixed 8192 (profiles/r02_shape_sweep.md)
-    p.waves_per_cu = beyond_cache ? (sh.dtype == 0 || packed ? 8 : (sh.pattern == PATTERN_COMPACT ? 0 : 12)) : 0;
+    // (round 4, on placed output buffers -- tolfg_batch_alloc_outputs -- the cap matters less: fp64 mixed 8192 cap 6 / 8 / 10 / 12 /
+    // none -> 314.9 / 280.8 / 282.1 / 280.3 / 280.8 us; packed fp32 mixed 8192 cap 6 / 8 / 12 / 16 / none -> 181.0 / 158.8 / 154.7 / 154.7 /
+    // 154.9 us: the packed kernels take 12 like the other fp32 launches, profiles/r04/plan_ab_placed.txt)
+    p.waves_per_cu = beyond_cache ? (sh.dtype == 0 ? 8 : (sh.pattern == PATTERN_COMPACT ? 0 : 12)) : 0;
     if (packed && sh.pattern == PATTERN_COMPACT) p.waves_per_cu = 0;
     p.xcd = 1;
     p.stagger = (!beyond_cache && tiles64 >= 12 * 256) ? 1 : 0;

@@ -415,7 +415,7 @@ void batch::eval(int B, const void *dX, long ldx, void *dF, long ldf, void *dG, 
     const int vmax = dtype_ == TOLFG_F64 ? 2 : 4;
     const bool aligned = (reinterpret_cast<uintptr_t>(dX) % 16 == 0) && (ldx % vmax == 0) &&
                          (!needF || ((reinterpret_cast<uintptr_t>(dF) % 16 == 0) && (ldf % vmax == 0)));
-    const LaunchPlan lp = plan_launch(LaunchShape{B, a.N, dtype_, a.pattern, mission_, aligned ? 1 : 0, out_bytes});
+    const LaunchPlan lp = plan_launch(LaunchShape{B, a.N, dtype_, a.pattern, mission_, aligned ? 1 : 0, out_bytes, needG ? 1 : 0});
     a.single = (!no_single && (lp.single || (force_single && B <= 8 && a.N <= 256 && mission_ != MISSION_MIXED))) ? 1 : 0;
     int max_nt = a.single ? 0 : (tile_nodes_forced_ > 0 ? tile_nodes_forced_ : lp.max_nt);
     if (!aligned && max_nt > 64) max_nt = 64;          // two nodes per lane (fp32 tiles beyond 64 nodes) need 16-byte rows

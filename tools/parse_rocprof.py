@@ -84,6 +84,20 @@ def main():
               f"({alg/(batch*ts):.1f} B per node)")
     md.append(f"- average duration {avg_ns/1e3:.2f} us  ->  **{alg/avg_ns:.1f} GB/s algorithmic = {alg/avg_ns/80:.1f} % of the "
               f"8 TB/s HBM3E peak** (profiled pass; bench.py's un-profiled HIP-event figure is in BENCH/DESIGN)")
+    plain = os.path.join(src, "bench_plain.json")
+    if os.path.exists(plain):
+        try:
+            with open(plain) as fh:
+                line = json.loads(fh.read().strip().splitlines()[-1])
+            r = line["roofline"]
+            md.append(f"- the same command WITHOUT the profiler, same box, same `gpurun` call, run just before: {1e3 * r['kernel_ms']:.2f} us per launch "
+                      f"(HIP events over the timed region) = {100 * r['frac']:.1f} % of peak; the bare store loop of the launch's shape on its buffers "
+                      f"{r.get('box_stream_shape_us') or float('nan'):.1f} us, vendor fill {r.get('box_fill_GBs') or float('nan'):.0f} GB/s; placement probe "
+                      f"{line['config'].get('output_placement', {}).get('probe_us')}.  Dispatch profiling lengthens every launch by 4-16 us "
+                      f"(profiles/r02_event_cost.md), and each process places its own output buffer (profiles/r04_allocation_classes.md): the "
+                      f"profiled process's store loop is the `store_shape_kernel` row above")
+        except (OSError, ValueError, KeyError, IndexError):
+            pass
     md.append("\n## HBM traffic of fg_kernel (PMC, per launch, averaged over "
               f"{len(fetch)} / {len(write)} dispatches)\n")
     md.append(f"- FETCH_SIZE {fetch_kib:.1f} KiB raw -> x2 (gfx950 wide-read correction) = {read_bytes/1e6:.2f} MB read; "

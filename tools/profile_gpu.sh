@@ -8,6 +8,8 @@ ARGS=${2:-"--steps 50 --warmup 5 --no-cpu-baseline --no-configs --no-calibration
 OUT=$PWD/gpurun_out/prof_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
 export TMPDIR=/tmp
+echo "[profile] the same command without the profiler (same box, same call): its own HIP-event figure goes beside the profiler's"
+python3 bench.py ${ARGS/--no-calibration/} > "$OUT/bench_plain.json" 2> "$OUT/bench_plain.err"
 echo "[profile] kernel trace + stats"
 timeout -k 5 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o stats -- python3 bench.py $ARGS > "$OUT/bench_stats.log" 2>&1
 echo "[profile] pmc FETCH_SIZE"
