@@ -63,7 +63,19 @@ int main(int argc, char **argv) {
         const LaunchPlan mix32u = plan_launch(LaunchShape{8192, 200, 1, PATTERN_REFERENCE, MISSION_MIXED, 0, 800e6});
         if (small.nt_stores || small.waves_per_cu || !small.fused || !small.xcd || small.max_nt != 64 || small.stagger) rc = 4;
         if (!big.nt_stores || big.waves_per_cu != 8 || !big.fused || big32.waves_per_cu != 12 || bigc.fused || big.stagger) rc = 5;
-        if (!mid.stagger || mid.nt_stores || big32.max_nt != 64 || mix32.max_nt != 128 || mix32.waves_per_cu != 8 || mix32u.max_nt != 64) rc = 6;
+        if (!mid.stagger || mid.nt_stores || big32.max_nt != 64 || mix32.max_nt != 128 || mix32.waves_per_cu != 12 || mix32u.max_nt != 64) rc = 6;
+        // round 4: a tile's rows through LDS in two passes for fp64 launches in the cache with 11-17 tile waves per CU; the cache switch at 240 MiB
+        const LaunchPlan near = plan_launch(LaunchShape{1280, 200, 0, PATTERN_REFERENCE, MISSION_S10, 1, 236e6});
+        const LaunchPlan far = plan_launch(LaunchShape{1536, 200, 0, PATTERN_REFERENCE, MISSION_S10, 1, 283e6});
+        const LaunchPlan mid32 = plan_launch(LaunchShape{1024, 200, 1, PATTERN_REFERENCE, MISSION_S10, 1, 95e6});
+        if (mid.sub_nodes != 32 || small.sub_nodes || big.sub_nodes || mid32.sub_nodes || near.sub_nodes || near.nt_stores || !far.nt_stores) rc = 8;
+        // round 4: the callback's single trajectory of 100+ nodes with the Jacobian wanted runs as tiles of <= 28 nodes (>= 5 of them)
+        const LaunchPlan cb200 = plan_launch(LaunchShape{1, 200, 0, PATTERN_REFERENCE, MISSION_S10, 1, 184e3, 1});
+        const LaunchPlan cb100 = plan_launch(LaunchShape{1, 100, 0, PATTERN_REFERENCE, MISSION_S10, 1, 92e3, 1});
+        const LaunchPlan cbF = plan_launch(LaunchShape{1, 200, 0, PATTERN_REFERENCE, MISSION_S10, 1, 13e3, 0});
+        const LaunchPlan cb60 = plan_launch(LaunchShape{1, 60, 0, PATTERN_REFERENCE, MISSION_S10, 1, 55e3, 1});
+        const LaunchPlan few = plan_launch(LaunchShape{4, 200, 0, PATTERN_REFERENCE, MISSION_S10, 1, 740e3, 1});
+        if (cb200.single || cb200.max_nt != 28 || cb100.single || cb100.max_nt != 20 || !cbF.single || !cb60.single || !few.single || small.single) rc = 9;
         for (int cap : {128, 100}) {
             int tiles, nt; plan_tiles(200, 1, cap, &tiles, &nt);
             if (tiles != 2 || nt != 100) rc = 7;
