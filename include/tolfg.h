@@ -305,7 +305,7 @@ int  tolfg_batch_objectives(tolfg_batch *b, int B, const void *dF, long ldf, voi
  *     Blocking, tens of ms: set-up time.  Free the buffer with tolfg_device_free.
  * Buffers from anywhere else keep working; they just take the class they land in. */
 int  tolfg_device_alloc(int device, size_t bytes, void **ptr);
-int  tolfg_device_free(void *ptr);
+int  tolfg_device_free(void *ptr);      /* waits for the device first, like hipFree does */
 int  tolfg_batch_alloc_outputs(tolfg_batch *b, int B, int tries, void **dG, long *ldg, double *probe_us, int *tried);
 
 /* Measurement aid.  While enabled, every tolfg_batch_eval attaches a start and a stop HIP event to its dispatches

@@ -85,3 +85,24 @@ def test_outputs_in_a_placed_buffer_match_the_oracle(tolfg, oracle, mission, dty
             assert_close(dF[t, :len(Fo)].cpu().numpy(), Fo, what=f"F[{t}]")
             assert_close(dG[t, :len(Go)].cpu().numpy(), Go, mask=o.undefined_mask(), what=f"G[{t}]")
     bt.close()
+
+
+@pytest.mark.gpu
+def test_dropping_a_placed_buffer_while_a_launch_still_writes_it_is_safe(tolfg):
+    """tolfg_device_free waits for the device before it unmaps (hipFree does by itself): a tensor dropped right behind an
+    evaluation -- no synchronisation in between -- must not pull the memory from under the kernel."""
+    import torch
+    B = 600
+    trajs = [tolfg.Trajectory(aircraft=0, radius_goal=100.0, Vref=1.0 + 0.01 * t) for t in range(B)]
+    bt = tolfg.Batch("S10", ["tempest"], ts=200)
+    bt.set_trajectories(trajs)
+    keepX, keepF, _ = bt.alloc(B)
+    bt.x0_device(keepX)
+    for trial in range(12):
+        G = bt.alloc_outputs(B)
+        bt.eval(keepX, keepF, G)
+        del G                       # the launch may still be running
+        gc.collect()
+    torch.cuda.synchronize()
+    assert torch.isfinite(keepF[:, :bt.neF]).all()
+    bt.close()

@@ -1055,8 +1055,18 @@ __device__ __forceinline__ void run_tile(const FgArgs &a, T *lds, int item, int 
 // Fused form (a.fused): the wave that arrives last at its trajectory's counter also finalizes it, so
 // an evaluation is one launch; otherwise finalize_kernel follows.
 // (A persistent form with per-XCD tile queues was measured 12-25 % slower: profiles/r02_persistent.md keeps the patch.)
+// Register budget.  The fp64 reference-pattern kernels with the wind models the reference itself uses (none, shear) are held to
+// 128 VGPRs = 4 waves per SIMD = 16 per CU: with their rows going through LDS in two passes (FgArgs::sub_nodes) that many fit
+// the LDS too, and the launches in the cache are bound by exactly that residency (they compile to 133-135 registers otherwise, to
+// 128 without spilling when asked).  The table / grid wind and compact-pattern variants would spill (56-190 bytes of scratch) and
+// keep the compiler's own allocation; the fp32 kernels are far below the limit anyway.
+template <typename T, int WIND, int PAT> constexpr int min_waves_per_simd()
+{
+    return (sizeof(T) == 8 && PAT == PATTERN_REFERENCE && (WIND == WIND_NONE || WIND == WIND_SHEAR)) ? 4 : TOLFG_MIN_WAVES_PER_SIMD;
+}
+
 template <typename T, int MISSION, int WIND, int VEC, int PAT, bool NT, int NP>
-__global__ __launch_bounds__(TILE, TOLFG_MIN_WAVES_PER_SIMD) void fg_kernel(const FgArgs a)
+__global__ __launch_bounds__(TILE, (min_waves_per_simd<T, WIND, PAT>())) void fg_kernel(const FgArgs a)
 {
     // dynamic LDS: (nt + 1) * RS elements are used; the launch may request more to cap the waves per CU
     // (fewer concurrent store streams suit the HBM write path better)

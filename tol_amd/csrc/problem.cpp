@@ -97,6 +97,8 @@ void release_block(void *ptr, DeviceBlock &b)
 {
     (void)hipSetDevice(b.device);
     if (b.chunk == 0) { (void)hipFree(ptr); return; }
+    // hipFree waits for the device by itself; unmapping does not, and a launch still writing the range would fault
+    (void)hipDeviceSynchronize();
     (void)hipMemUnmap(ptr, b.bytes);
     for (hipMemGenericAllocationHandle_t h : b.handles) (void)hipMemRelease(h);
     (void)hipMemAddressFree(ptr, b.bytes);
