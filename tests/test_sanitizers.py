@@ -64,11 +64,13 @@ int main(int argc, char **argv) {
         if (small.nt_stores || small.waves_per_cu || !small.fused || !small.xcd || small.max_nt != 64 || small.stagger) rc = 4;
         if (!big.nt_stores || big.waves_per_cu != 8 || !big.fused || big32.waves_per_cu != 12 || bigc.fused || big.stagger) rc = 5;
         if (!mid.stagger || mid.nt_stores || big32.max_nt != 64 || mix32.max_nt != 128 || mix32.waves_per_cu != 12 || mix32u.max_nt != 64) rc = 6;
-        // round 4: a tile's rows through LDS in two passes for fp64 launches in the cache with 11-17 tile waves per CU; the cache switch at 240 MiB
+        // round 4: a tile's rows through LDS in two passes for fp64 launches in the cache with 11-20 tile waves per CU; the cache switch at 240 MiB
         const LaunchPlan near = plan_launch(LaunchShape{1280, 200, 0, PATTERN_REFERENCE, MISSION_S10, 1, 236e6});
         const LaunchPlan far = plan_launch(LaunchShape{1536, 200, 0, PATTERN_REFERENCE, MISSION_S10, 1, 283e6});
         const LaunchPlan mid32 = plan_launch(LaunchShape{1024, 200, 1, PATTERN_REFERENCE, MISSION_S10, 1, 95e6});
-        if (mid.sub_nodes != 32 || small.sub_nodes || big.sub_nodes || mid32.sub_nodes || near.sub_nodes || near.nt_stores || !far.nt_stores) rc = 8;
+        const LaunchPlan ten = plan_launch(LaunchShape{640, 200, 0, PATTERN_REFERENCE, MISSION_S10, 1, 118e6});
+        if (mid.sub_nodes != 32 || small.sub_nodes || ten.sub_nodes || big.sub_nodes || mid32.sub_nodes || near.sub_nodes != 32 || near.nt_stores ||
+            !far.nt_stores || far.sub_nodes) rc = 8;
         // round 4: the callback's single trajectory of 100+ nodes with the Jacobian wanted runs as tiles of <= 28 nodes (>= 5 of them)
         const LaunchPlan cb200 = plan_launch(LaunchShape{1, 200, 0, PATTERN_REFERENCE, MISSION_S10, 1, 184e3, 1});
         const LaunchPlan cb100 = plan_launch(LaunchShape{1, 100, 0, PATTERN_REFERENCE, MISSION_S10, 1, 92e3, 1});

@@ -74,7 +74,7 @@ struct FgArgs {
                            // 0 = finalize_kernel follows fg_kernel
     int  stagger;          // 1 = waves take an issue priority from their slot on the SIMD (launches whose waves all start together)
     int  sub_nodes;        // 0 = a tile's Jacobian rows go through LDS all at once; 32 = in passes of 32 nodes (less LDS per
-                           // wave: 16 instead of 10 resident fp64 tile waves per CU); one node per lane, tile-per-workgroup kernel only
+                           // wave: 16 instead of 10 resident fp64 tile waves per CU); fp64, tile-per-workgroup kernel only
     int  nt_stores;        // 1 = the slab stream carries the non-temporal hint (outputs beyond the Infinity Cache)
     int  store_shape;      // measurement aid: 1 = launch store_shape_kernel (this launch's grid, tile order, LDS request and
                            // store flavour around nothing but the slab stores) instead of the evaluation

@@ -767,7 +767,9 @@ __device__ __forceinline__ void tile_body(const FgArgs &a, T *lds, int item, int
     if (a.needG) {
         // idle lanes (lane >= cnt) leave no row: the workgroup's LDS holds a.nt + 1 rows, not TN + 1; the second
         // component of a lane whose second node lies beyond the tile writes the spare row, which nobody reads
-        if constexpr (NP == 1) {
+        if constexpr (NP == 1 && sizeof(T) == 8) {
+            // (fp64 only: fp32 rows are half the size and never the limit, and the pass loop costs registers -- it kept the fp32
+            // kernels at 141 VGPRs instead of 88)
             // The rows go through LDS a.sub_nodes nodes at a time (0 = the whole tile at once): a tile of 52 fp64 nodes
             // holds 14.8 KB of rows, which caps a CU at 10 resident tile waves; with 32-node passes the same LDS space
             // (9.2 KB) serves the tile in two passes and 16 waves fit.  A pass is a sub-tile to the stream: 32 nodes of
@@ -798,11 +800,22 @@ __device__ __forceinline__ void tile_body(const FgArgs &a, T *lds, int item, int
             }
         } else {
             if (act[0]) {
-                T *row = lds + (lane + 1) * RS;
-                T *row1 = act[NP - 1] ? row + TILE * RS : lds;
-                nc.jacobian(f, RowPair{row, row1});
-                row[SL_ZERO] = T(0); row[SL_ONE] = T(1); row[SL_MONE] = T(-1);
-                row1[SL_ZERO] = T(0); row1[SL_ONE] = T(1); row1[SL_MONE] = T(-1);
+                T *row = lds + (lane + 1) * RS;          // rows follow one spare row (SlabStream)
+                if constexpr (NP == 1) {
+#if defined(TOLFG_STAMPS) || defined(TOLFG_ABLATE)
+                    if (TOLFG_VARIANT(a) & 256) {
+#pragma unroll
+                        for (int i = 0; i < 32; i++) row[i] = s[i % NI];
+                    } else
+#endif
+                    nc.jacobian(f, row);
+                    row[SL_ZERO] = T(0); row[SL_ONE] = T(1); row[SL_MONE] = T(-1);
+                } else {
+                    T *row1 = act[NP - 1] ? row + TILE * RS : lds;
+                    nc.jacobian(f, RowPair{row, row1});
+                    row[SL_ZERO] = T(0); row[SL_ONE] = T(1); row[SL_MONE] = T(-1);
+                    row1[SL_ZERO] = T(0); row1[SL_ONE] = T(1); row1[SL_MONE] = T(-1);
+                }
             }
             __syncthreads();
             TOLFG_STAMP(a, 3);
@@ -1227,7 +1240,7 @@ hipError_t launch_vec(const FgArgs &a, int vec, dim3 grid, hipStream_t s, hipEve
     // Timing events ride on the dispatches themselves (hipExtLaunchKernelGGL: the kernel's own start / end
     // timestamps, no extra commands on the stream): t0 = start of fg_kernel, t1 = end of the evaluation's
     // last kernel (fg_kernel when fused, else finalize_kernel).
-    const unsigned lds = (unsigned)fg_lds_request(sizeof(T) == 8 ? 0 : 1, a.waves_per_cu, a.nt, NP == 1 ? a.sub_nodes : 0);
+    const unsigned lds = (unsigned)fg_lds_request(sizeof(T) == 8 ? 0 : 1, a.waves_per_cu, a.nt, sizeof(T) == 8 ? a.sub_nodes : 0);
     hipEvent_t fg_end = a.fused ? t1 : nullptr;
     auto go = [&](auto kernel, dim3 g, unsigned ldsz, hipEvent_t st, hipEvent_t en) {
         if (st || en) hipExtLaunchKernelGGL(kernel, g, dim3(TILE), ldsz, s, st, en, 0, a);
@@ -1594,7 +1607,7 @@ hipError_t launch_fg(const FgArgs &a, int mission, int wind, int dtype, int vec,
         return hipErrorInvalidValue;
     if (packed && (a.single || vec != 4)) return hipErrorInvalidValue;
     // rows through LDS in passes: 32 nodes of slabs are whole 16-byte vectors for every element size and pattern
-    if (a.sub_nodes != 0 && (a.sub_nodes != 32 || a.single || packed)) return hipErrorInvalidValue;
+    if (a.sub_nodes != 0 && (a.sub_nodes != 32 || a.single || dtype != 0)) return hipErrorInvalidValue;
     if ((a.fused || a.done) && !a.counter) return hipErrorInvalidValue;
     if (a.done && !a.fused && !a.single) return hipErrorInvalidValue;     // finalize_kernel would still be running
     if (a.tail_count < 0 || a.tail_count > a.B) return hipErrorInvalidValue;

@@ -54,7 +54,11 @@ LaunchPlan plan_launch(const LaunchShape &sh)
     //    1088: 31.6 -> 30.1, 34.7 -> 34.0, 42.1 -> 40.1 and 41.6 -> 40.7 on two boxes, 46.9 -> 45.5; G7 768 / 1024: 31.7 -> 29.9, 43.6 ->
     //    41.3; mixed 768 / 1024 / 1088: 31.5 -> 30.0, 43.7 -> 42.0 (one box: 38.5 -> 39.5), 47.0 -> 45.0); nothing at <= 10 waves per
     //    CU (B = 256, 512, 640: they all fit anyway) or from 18 up (1152 ... 2048), where the CU's store path, not residency, sets
-    //    the pace (profiles/r04_incache_counters.md).  fp32 rows are half the size and never the limit.
+    //    the pace (profiles/r04_incache_counters.md).  fp32 rows are half the size and never the limit.  With these kernels held to
+    //    128 VGPRs (kernels.hip: min_waves_per_simd; the two-pass loop itself had pushed them to 133-135 = 12 waves per CU) the gain
+    //    grew and the range widened: S10 704 / 896 / 1024 / 1088 / 1152 / 1280: 31.6 -> 28.2, 35.3 -> 34.0, 45.4 -> 40.1, 44.7 -> 41.1,
+    //    47.6 -> 44.2, 50.6 -> 49.4 us; mixed 1024 45.1 -> 39.3, G7 1024 44.9 -> 38.7; nothing at 640 (10 per CU) and from 1408 on
+    //    (beyond the cache): 11-20 tile waves per CU (profiles/r04/sub32_sweep_128vgpr.txt).
     //  * round 4, the SNOPT callback (B = 1) at ts >= 100 as tile workgroups on different CUs with the completion word instead of
     //    one workgroup of 2-4 waves, every tile wave fetching the finalizer's x values (dt, node 0, node N) at its start: ts = 200
     //    19.8 us per call as one workgroup, 17.2 / 16.8 / 16.4 / 16.2 as 4 / 5 / 7 / 8 tile workgroups; ts = 100 16.8 as one workgroup,
@@ -75,7 +79,7 @@ LaunchPlan plan_launch(const LaunchShape &sh)
         p.max_nt = ((sh.N + t - 1) / t + 3) & ~3;
     }
     const long waves_per_cu_launched = (tiles64 + kCUs - 1) / kCUs;
-    p.sub_nodes = (!beyond_cache && sh.dtype == 0 && !p.single && waves_per_cu_launched > 10 && waves_per_cu_launched <= 17) ? 32 : 0;
+    p.sub_nodes = (!beyond_cache && sh.dtype == 0 && !p.single && waves_per_cu_launched > 10 && waves_per_cu_launched <= 20) ? 32 : 0;
     p.nt_stores = beyond_cache ? 1 : 0;
     // fp32 compact slabs (184 bytes per node) are the one shape that wants every wave it can get beyond the cache
     // too: cap 12 / none -> 55.1 / 50.7 us at B=4096, 112.0 / 106.0 us for the mixed 8192 (profiles/r02_shape_sweep.md)
