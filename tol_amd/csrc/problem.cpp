@@ -91,7 +91,7 @@ struct DeviceBlock {
 };
 std::mutex g_blocks_mu;
 std::map<void *, DeviceBlock> g_blocks;
-constexpr size_t kPlacedChunk = 2u << 20;
+constexpr size_t kPlacedChunkDefault = 2u << 20;
 
 void release_block(void *ptr, DeviceBlock &b)
 {
@@ -108,6 +108,12 @@ void release_block(void *ptr, DeviceBlock &b)
 void *device_alloc(int device, size_t bytes)
 {
     if (bytes == 0) throw std::invalid_argument("device_alloc: zero bytes");
+    // measurement: TOLFG_PLACED_CHUNK_KIB=k backs the range with chunks of k KiB (a power of two, 64 ... 1048576) instead of 2 MiB
+    size_t kPlacedChunk = kPlacedChunkDefault;
+    if (const char *e = std::getenv("TOLFG_PLACED_CHUNK_KIB")) {
+        const long k = std::atol(e);
+        if (k >= 64 && k <= (1L << 20) && (k & (k - 1)) == 0) kPlacedChunk = (size_t)k << 10;
+    }
     check(hipSetDevice(device), "hipSetDevice");
     DeviceBlock blk;
     blk.device = device;
