@@ -19,7 +19,7 @@ def assert_close(got, ref, tol=RTOL64, mask=None, what=""):
         bad &= ~mask
     assert not bad.any(), f"{what}: non-finite output at {np.flatnonzero(bad)[:8]}"
     worst = int(np.argmax(err))
-    assert err[worst] <= tol, f"{what}: worst scaled error {err[worst]:.3e} at {worst}: {got.flat[worst]!r} vs {ref.flat[worst]!r}"
+    assert err.flat[worst] <= tol, f"{what}: worst scaled error {err.flat[worst]:.3e} at {np.unravel_index(worst, err.shape)}: {got.flat[worst]!r} vs {ref.flat[worst]!r}"
     return float(err.max()) if err.size else 0.0
 
 
