@@ -136,7 +136,8 @@ _hip_runtime = None
 
 
 def lib_path():
-    return os.path.join(HERE, "lib", "libtolfg.so")
+    """The product library; TOLFG_LIBRARY names another build of it (same-box A/B of two builds, tools/)."""
+    return os.environ.get("TOLFG_LIBRARY") or os.path.join(HERE, "lib", "libtolfg.so")
 
 
 def hip_runtime_path():
