@@ -73,6 +73,13 @@ __device__ constexpr SlabTableCompact kSlabCompact = make_compact_table();
 
 constexpr int gcd_c(int a, int b) { return b == 0 ? a : gcd_c(b, a % b); }
 
+// The kernels that can send a tile's rows through LDS in two passes (FgArgs::sub_nodes) and are held to 128 VGPRs so that 16 of
+// their waves fit a CU: fp64, reference pattern, the wind models the reference itself uses (none, shear).
+template <typename T, int WIND, int PAT> constexpr bool two_pass_family()
+{
+    return sizeof(T) == 8 && PAT == PATTERN_REFERENCE && (WIND == WIND_NONE || WIND == WIND_SHEAR);
+}
+
 #ifdef TOLFG_STAMPS
 #define TOLFG_STAMP(a, slot)                                                                         \
     do {                                                                                             \
@@ -767,9 +774,10 @@ __device__ __forceinline__ void tile_body(const FgArgs &a, T *lds, int item, int
     if (a.needG) {
         // idle lanes (lane >= cnt) leave no row: the workgroup's LDS holds a.nt + 1 rows, not TN + 1; the second
         // component of a lane whose second node lies beyond the tile writes the spare row, which nobody reads
-        if constexpr (NP == 1 && sizeof(T) == 8) {
-            // (fp64 only: fp32 rows are half the size and never the limit, and the pass loop costs registers -- it kept the fp32
-            // kernels at 141 VGPRs instead of 88)
+        if constexpr (NP == 1 && two_pass_family<T, WIND, PAT>()) {
+            // (only the kernel family that is also held to 128 VGPRs, min_waves_per_simd: fp32 rows are half the size and never the
+            // limit, the other fp64 variants could not use the residency anyway, and the pass loop costs registers -- it kept the
+            // fp32 kernels at 141 VGPRs instead of 88)
             // The rows go through LDS a.sub_nodes nodes at a time (0 = the whole tile at once): a tile of 52 fp64 nodes
             // holds 14.8 KB of rows, which caps a CU at 10 resident tile waves; with 32-node passes the same LDS space
             // (9.2 KB) serves the tile in two passes and 16 waves fit.  A pass is a sub-tile to the stream: 32 nodes of
@@ -1075,7 +1083,7 @@ __device__ __forceinline__ void run_tile(const FgArgs &a, T *lds, int item, int 
 // keep the compiler's own allocation; the fp32 kernels are far below the limit anyway.
 template <typename T, int WIND, int PAT> constexpr int min_waves_per_simd()
 {
-    return (sizeof(T) == 8 && PAT == PATTERN_REFERENCE && (WIND == WIND_NONE || WIND == WIND_SHEAR)) ? 4 : TOLFG_MIN_WAVES_PER_SIMD;
+    return two_pass_family<T, WIND, PAT>() ? 4 : TOLFG_MIN_WAVES_PER_SIMD;
 }
 
 template <typename T, int MISSION, int WIND, int VEC, int PAT, bool NT, int NP>
@@ -1240,7 +1248,7 @@ hipError_t launch_vec(const FgArgs &a, int vec, dim3 grid, hipStream_t s, hipEve
     // Timing events ride on the dispatches themselves (hipExtLaunchKernelGGL: the kernel's own start / end
     // timestamps, no extra commands on the stream): t0 = start of fg_kernel, t1 = end of the evaluation's
     // last kernel (fg_kernel when fused, else finalize_kernel).
-    const unsigned lds = (unsigned)fg_lds_request(sizeof(T) == 8 ? 0 : 1, a.waves_per_cu, a.nt, sizeof(T) == 8 ? a.sub_nodes : 0);
+    const unsigned lds = (unsigned)fg_lds_request(sizeof(T) == 8 ? 0 : 1, a.waves_per_cu, a.nt, two_pass_family<T, WIND, PAT>() ? a.sub_nodes : 0);
     hipEvent_t fg_end = a.fused ? t1 : nullptr;
     auto go = [&](auto kernel, dim3 g, unsigned ldsz, hipEvent_t st, hipEvent_t en) {
         if (st || en) hipExtLaunchKernelGGL(kernel, g, dim3(TILE), ldsz, s, st, en, 0, a);
@@ -1607,7 +1615,8 @@ hipError_t launch_fg(const FgArgs &a, int mission, int wind, int dtype, int vec,
         return hipErrorInvalidValue;
     if (packed && (a.single || vec != 4)) return hipErrorInvalidValue;
     // rows through LDS in passes: 32 nodes of slabs are whole 16-byte vectors for every element size and pattern
-    if (a.sub_nodes != 0 && (a.sub_nodes != 32 || a.single || dtype != 0)) return hipErrorInvalidValue;
+    if (a.sub_nodes != 0 && (a.sub_nodes != 32 || a.single || dtype != 0 || a.pattern != PATTERN_REFERENCE || (wind != WIND_NONE && wind != WIND_SHEAR)))
+        return hipErrorInvalidValue;
     if ((a.fused || a.done) && !a.counter) return hipErrorInvalidValue;
     if (a.done && !a.fused && !a.single) return hipErrorInvalidValue;     // finalize_kernel would still be running
     if (a.tail_count < 0 || a.tail_count > a.B) return hipErrorInvalidValue;

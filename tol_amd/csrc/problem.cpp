@@ -476,7 +476,9 @@ void batch::eval(int B, const void *dX, long ldx, void *dF, long ldf, void *dG, 
     a.waves_per_cu = waves_forced_ ? waves_per_cu_ : lp.waves_per_cu;
     a.nt_stores = nt_forced_ >= 0 ? nt_forced_ : lp.nt_stores;
     a.stagger = (stagger_forced_ >= 0 ? stagger_forced_ : lp.stagger) && !a.single ? 1 : 0;
-    a.sub_nodes = (!a.single && dtype_ == TOLFG_F64 && a.nt > 32 && a.nt <= kTileNodes) ? (sub_forced_ >= 0 ? sub_forced_ : lp.sub_nodes) : 0;
+    const int kwind = kernel_wind(windmodel_);
+    a.sub_nodes = (!a.single && dtype_ == TOLFG_F64 && a.pattern == PATTERN_REFERENCE && (kwind == WIND_NONE || kwind == WIND_SHEAR) && a.nt > 32 &&
+                   a.nt <= kTileNodes) ? (sub_forced_ >= 0 ? sub_forced_ : lp.sub_nodes) : 0;
     a.xcd_chunk = ((xcd_forced_ >= 0 ? xcd_forced_ : lp.xcd) && !a.single) ? (int)(a.tail_count ? body / 8 : (W + 7) / 8) : 0;
     a.X = dX; a.ldx = ldx; a.F = dF; a.ldf = ldf; a.G = dG; a.ldg = ldg;
     a.wind = dWind; a.traj = d_traj_;
