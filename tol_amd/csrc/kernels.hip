@@ -22,8 +22,15 @@
 //     waves per CU (the kernel is bound by the HBM write path, which serves fewer concurrent store
 //     streams better) and the slab stream is non-temporal; when they fit, plain stores, no cap, and the
 //     waves take issue priorities from their SIMD slots so that they do not run in step (FgArgs::stagger).
+//     Launches within the cache with 11-20 tile waves per CU are bound by how many of them a CU holds: the fp64
+//     reference-pattern kernels send a tile's rows through LDS in two 32-node passes (FgArgs::sub_nodes: 9.2 instead of
+//     14.8 KB per wave) and are held to 128 VGPRs (min_waves_per_simd), so that 16 fit instead of 10.
 //   * callback path (a few short trajectories): fg_single_kernel, whole trajectory per workgroup,
-//     one launch, optional completion word for the spinning host.
+//     one launch, optional completion word for the spinning host; the callback's single trajectory of 100+ nodes
+//     with the Jacobian wanted goes through fg_kernel as 5-8 tile workgroups on different CUs instead (every tile
+//     wave fetches the finalizer's x values at its start: run_tile).
+//   * set-up kernels: x0_kernel (initial guesses, one thread per node, bitwise the serial walk), bounds_kernel;
+//     store_shape_kernel is a measurement aid (the launch's shape with only the slab stores in it).
 //   * a mixed batch (MISSION_MIXED) reads each trajectory's mission from its record; a tile is one
 //     trajectory, so the branch is wave-uniform.
 //   * the SNOPT-facing layouts are node-major (x[11k+1+m], G slab c0+104k), so a lane-per-node
