@@ -58,9 +58,16 @@ class _DeviceBlock:
 
 
 def _owned_tensor(ptr, shape, dtype, device):
+    """A torch view of a tolfg_device_alloc block.  torch takes the device from the pointer's attributes; should it see the
+    block anywhere else than on `device` it would hand back a COPY (and the placement would be lost without a word), so
+    the pointer is checked and a mismatch is an error the caller can fall back from."""
     import torch
     blk = _DeviceBlock(ptr, shape, "<f8" if dtype == "f64" else "<f4")
-    return torch.as_tensor(blk, device=torch.device("cuda", device))
+    t = torch.as_tensor(blk, device=torch.device("cuda", device))
+    if t.data_ptr() != ptr or t.device.index != device:
+        del t
+        raise capi.TolfgError(capi.ERR_HIP, "torch did not adopt the placed block in place (device attribution of the pointer)")
+    return t
 
 
 def device_alloc(shape, dtype="f64", device=0):
@@ -354,10 +361,15 @@ class Batch:
         F = torch.zeros((B, up(self.neF)), dtype=dt, device=dev)
         if placed is None:
             placed = pad is None and 0 < B <= getattr(self, "B", 0)
+        G = None
         if placed:
-            G = self.alloc_outputs(B, tries)
-            G.zero_()
-        else:
+            try:
+                G = self.alloc_outputs(B, tries)
+                G.zero_()
+            except capi.TolfgError as exc:      # the buffer is a convenience, not a requirement: torch's allocator then
+                G = None
+                self.placement = {"allocator": "torch (the placed allocation was not available: %s)" % exc, "candidates": 0, "probe_us": []}
+        if G is None:
             G = torch.zeros((B, up(self.neG)), dtype=dt, device=dev)
         return X, F, G
 
