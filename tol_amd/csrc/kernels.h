@@ -144,10 +144,13 @@ hipError_t launch_sum(const void *v, int B, int dtype, double *out, hipStream_t 
 
 // Initial guess of B trajectories straight into device rows (ref: problemS10::InitialCond /
 // problemG7::InitialCond); bounds likewise (ref: problem::setLimits).  One-time set-up kernels.
-// tgrid: device table [2][N+1] of the node times t_k = t_(k-1) + dt, added up on the host (S10: dt = 20/N, then G7: dt =
-// 10/N) -- the node-parallel kernel, one workgroup per trajectory; nullptr = the serial reference form, one thread
-// per trajectory (bitwise the same rows)
-hipError_t launch_x0(const FgArgs &a, int mission, int dtype, const double *tgrid, hipStream_t s);
+// tab: device table [2 missions][X0_FIELDS][N+1].  Field 0 of either mission holds the node times t_k = t_(k-1) + dt,
+// added up on the host (S10: dt = 20/N, G7: dt = 10/N); launch_x0_table fills the other fields from them once (everything
+// of a node's row that is the same for all trajectories of a mission); launch_x0 then runs the node-parallel kernel, one
+// workgroup per trajectory.  tab == nullptr = the serial reference form, one thread per trajectory (bitwise the same rows).
+constexpr int X0_FIELDS = 10;
+hipError_t launch_x0_table(double *tab, int N, int mission, hipStream_t s);
+hipError_t launch_x0(const FgArgs &a, int mission, int dtype, const double *tab, hipStream_t s);
 struct BoundsArgs {
     void *xlow, *xupp; long ldx;
     void *Flow, *Fupp; long ldf;

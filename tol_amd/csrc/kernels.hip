@@ -1313,12 +1313,17 @@ hipError_t launch_mission(const FgArgs &a, int mission, int wind, int vec, dim3 
 // setup.cpp::initial_guess, whose operations these kernels repeat one for one).
 __device__ __forceinline__ double atan2_t(double y, double x) { return atan2(y, x); }
 
-// Everything InitialCond computes at ONE node from the node's time alone: position, air-relative speed, the course
-// before it is made continuous, flight-path angle, bank, lift coefficient, thrust.
+// Everything InitialCond computes at ONE node, in two parts.  x0_shape: what depends on the mission and the node's time
+// alone -- the flown curve's sine and cosine, air-relative speed, the course before chi_d is added and before it is made
+// continuous, flight-path angle, the load-factor magnitude, bank, and the specific force along the velocity: the same
+// for every trajectory of a mission, so the node-parallel form computes it ONCE per (mission, node) into a table
+// (x0_table_kernel).  x0_finish: what the trajectory adds -- start offset, chi_d, the aircraft (lift coefficient, drag,
+// thrust).  x0_node = finish(shape) is what the serial form evaluates per node.
+struct X0Shape { double s, c, Va, chi0, gam, nmag, phi, dot; };
 struct X0Node { double p[3], Va, chi_raw, gam, phi, CL, thrust; };
 
 // FAST: atan2(+-0, x > 0) is +-0 by definition, and both missions' guesses have such arguments at every node (no vertical
-// motion: az = 0; G7 flies a straight line: ay = 0) -- the node-parallel kernel skips the library call there; the serial
+// motion: az = 0; G7 flies a straight line: ay = 0) -- the node-parallel form skips the library call there; the serial
 // reference form always calls it, and the two are compared bit for bit.
 template <bool FAST> __device__ __forceinline__ double x0_atan2(double y, double x)
 {
@@ -1327,29 +1332,26 @@ template <bool FAST> __device__ __forceinline__ double x0_atan2(double y, double
 }
 
 template <bool FAST>
-__device__ __forceinline__ X0Node x0_node(bool loiter, double t, const TrajDev &tr, const AcCoef &ac, double cd, double sd)
+__device__ __forceinline__ X0Shape x0_shape(bool loiter, double t)
 {
-    constexpr double kRho = 1.2682, kPi = 3.14159265358979323846;
+#pragma clang fp contract(off)      // every operation rounded on its own, as the host's build of InitialCond does: the serial and the node-parallel form then agree by construction
+    constexpr double kPi = 3.14159265358979323846;
     const double tfinal = loiter ? 20.0 : 10.0;
     const double ax = loiter ? 100.0 : 40.0, ay = loiter ? 100.0 : 0.0, az = 0.0;
     const double w = 2.0 * kPi / tfinal;
-    const double s = sin(w * t), c = cos(w * t);     // (sincos() shares the reduction but differs from these in the last bit at some nodes)
-    X0Node o;
+    X0Shape o;
+    o.s = sin(w * t); o.c = cos(w * t);     // (sincos() shares the reduction but differs from these in the last bit at some nodes)
+    const double s = o.s, c = o.c;
     double v[3], acc[3];
     if (loiter) {
-        o.p[0] = ax * s - ax + tr.xi;   o.p[1] = -ay * c + tr.yi;      o.p[2] = az * c - az + tr.zi;
         v[0] = w * ax * c;              v[1] = w * ay * s;             v[2] = -w * az * s;
         acc[0] = -w * w * ax * s;       acc[1] = w * w * ay * c;       acc[2] = -w * w * az * c;
     } else {
-        const double px = ax / tfinal * t + tr.xi, py = -ay * c + ay + tr.yi;
-        o.p[0] = cd * px - sd * py;
-        o.p[1] = sd * px + cd * py;
-        o.p[2] = az * c - az + tr.zi;
         v[0] = ax / tfinal;             v[1] = ay * w * s;             v[2] = -az * w * s;
         acc[0] = 0.0;                   acc[1] = ay * w * w * c;       acc[2] = -az * w * w * c;
     }
     o.Va = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
-    o.chi_raw = x0_atan2<FAST>(v[1], v[0]) + (loiter ? 0.0 : tr.chi_d);
+    o.chi0 = x0_atan2<FAST>(v[1], v[0]);
     const double h2 = v[0] * v[0] + v[1] * v[1];
     o.gam = (FAST && v[2] == 0.0 && h2 > 0.0) ? -v[2] : atan2_t(-v[2], sqrt(h2));       // atan2(+-0, sqrt(h2) > 0) = +-0
     const double u[3] = {v[0] / o.Va, v[1] / o.Va, v[2] / o.Va};
@@ -1357,18 +1359,49 @@ __device__ __forceinline__ X0Node x0_node(bool loiter, double t, const TrajDev &
     const double n0 = -sf[0] * (u[0] * u[0] - 1.0) - u[0] * u[1] * sf[1] - u[0] * u[2] * sf[2];
     const double n1 = -sf[1] * (u[1] * u[1] - 1.0) - u[0] * u[1] * sf[0] - u[1] * u[2] * sf[2];
     const double n2 = -sf[2] * (u[2] * u[2] - 1.0) - u[0] * u[2] * sf[0] - u[1] * u[2] * sf[1];
-    const double nmag = sqrt(n0 * n0 + n1 * n1 + n2 * n2);
-    const double l0 = -n0 / nmag, l1 = -n1 / nmag, l2 = -n2 / nmag;
+    o.nmag = sqrt(n0 * n0 + n1 * n1 + n2 * n2);
+    const double l0 = -n0 / o.nmag, l1 = -n1 / o.nmag, l2 = -n2 / o.nmag;
     o.phi = atan2_t(l0 * u[1] - l1 * u[0], l2);
-    o.CL = 2.0 * (ac.mm * nmag) / (kRho * o.Va * o.Va * ac.SS);
-    const double drag = 0.5 * kRho * o.Va * o.Va * ac.SS * (ac.Cd0 + o.CL * o.CL / (kPi * ac.AR * ac.ee));
-    o.thrust = ac.mm * (u[0] * sf[0] + u[1] * sf[1] + u[2] * sf[2]) + drag;
+    o.dot = u[0] * sf[0] + u[1] * sf[1] + u[2] * sf[2];
     return o;
+}
+
+__device__ __forceinline__ X0Node x0_finish(bool loiter, double t, const X0Shape &sh, const TrajDev &tr, const AcCoef &ac, double cd, double sd)
+{
+#pragma clang fp contract(off)
+    constexpr double kRho = 1.2682, kPi = 3.14159265358979323846;
+    const double tfinal = loiter ? 20.0 : 10.0;
+    const double ax = loiter ? 100.0 : 40.0, ay = loiter ? 100.0 : 0.0, az = 0.0;
+    const double s = sh.s, c = sh.c;
+    X0Node o;
+    if (loiter) {
+        o.p[0] = ax * s - ax + tr.xi;   o.p[1] = -ay * c + tr.yi;      o.p[2] = az * c - az + tr.zi;
+    } else {
+        const double px = ax / tfinal * t + tr.xi, py = -ay * c + ay + tr.yi;
+        o.p[0] = cd * px - sd * py;
+        o.p[1] = sd * px + cd * py;
+        o.p[2] = az * c - az + tr.zi;
+    }
+    o.Va = sh.Va;
+    o.chi_raw = sh.chi0 + (loiter ? 0.0 : tr.chi_d);
+    o.gam = sh.gam;
+    o.phi = sh.phi;
+    o.CL = 2.0 * (ac.mm * sh.nmag) / (kRho * o.Va * o.Va * ac.SS);
+    const double drag = 0.5 * kRho * o.Va * o.Va * ac.SS * (ac.Cd0 + o.CL * o.CL / (kPi * ac.AR * ac.ee));
+    o.thrust = ac.mm * sh.dot + drag;
+    return o;
+}
+
+template <bool FAST>
+__device__ __forceinline__ X0Node x0_node(bool loiter, double t, const TrajDev &tr, const AcCoef &ac, double cd, double sd)
+{
+    return x0_finish(loiter, t, x0_shape<FAST>(loiter, t), tr, ac, cd, sd);
 }
 
 // The one step of InitialCond that looks at the node before: the course is kept continuous from node to node.
 __device__ __forceinline__ double x0_unwrap(double chi, double chi_prev)
 {
+#pragma clang fp contract(off)
     constexpr double kPi = 3.14159265358979323846;
     double jump = chi - chi_prev;
     while (jump < -kPi || jump > kPi) {
@@ -1414,24 +1447,50 @@ __global__ void x0_serial_kernel(const FgArgs a)
     }
 }
 
-// Node-parallel form: one workgroup per trajectory, one thread per node, X0_NODES nodes per pass.  Only three things in
-// InitialCond look at the node before, and each has a parallel form whose result is the serial one bit for bit:
+// Node-parallel form: one workgroup per trajectory, one thread per node, X0_NODES nodes per pass.  What a node's row
+// holds beyond the trajectory's own start offset, chi_d and aircraft is the same for every trajectory of a mission:
+// x0_table_kernel computes it once per (mission, node) -- with the library's sin, cos, atan2, the square roots and
+// divisions of x0_shape -- and x0_kernel reads it back (X0_FIELDS doubles per node, from L2), which leaves three
+// divisions per node and makes the launch a writer of rows.  Only three things in InitialCond look at the node before,
+// and each has a parallel form whose result is the serial one bit for bit:
 //   * the node's time is the running sum t = t + dt: the host adds it up once per mission (the same IEEE additions)
-//     and the kernel reads t_k from that table (tgrid);
+//     and the kernels read t_k from that table (field 0);
 //   * the course is made continuous against the PREVIOUS node's continuous course: every node first takes a guess --
 //     its own course plus 2 pi times the number of wraps before it (a scan over the nodes of the jumps of the raw
 //     course) -- and then runs the reference's own step (x0_unwrap) against its neighbour's guess; where every node
 //     reproduces its guess, the guesses ARE the serial result (induction from node 0), otherwise -- never seen -- one
 //     thread redoes the pass serially;
-//   * the control rates are differences to the previous node's bank and lift coefficient: a neighbour read in LDS.
+//   * the control rates are differences to the previous node's bank (table: both nodes' banks are mission data) and
+//     lift coefficient (a neighbour read in LDS).
 // The rows leave through an LDS image of the pass (node-major, as in memory) with coalesced stores.
 constexpr int X0_NODES = 256;
+// table fields: [mission][field][node], field 0 = t (from the host)
+enum { X0F_T = 0, X0F_S, X0F_C, X0F_VA, X0F_CHI0, X0F_GAM, X0F_NMAG, X0F_PHI, X0F_DOT, X0F_DPHI };
+static_assert(X0F_DPHI + 1 == X0_FIELDS, "x0 table fields");
+
+template <int MISSION>
+__global__ __launch_bounds__(X0_NODES) void x0_table_kernel(double *tab, int N)
+{
+    const int m = MISSION == MISSION_MIXED ? (int)blockIdx.y : (MISSION == MISSION_S10 ? 0 : 1);
+    const bool loiter = (MISSION == MISSION_MIXED ? m == 0 : MISSION == MISSION_S10);
+    const int k = blockIdx.x * X0_NODES + threadIdx.x;
+    if (k > N) return;
+    const long ld = N + 1;
+    double *row = tab + (long)m * X0_FIELDS * ld;
+    const double dt = (loiter ? 20.0 : 10.0) / N;
+    const X0Shape sh = x0_shape<true>(loiter, row[X0F_T * ld + k]);
+    double dphi = 0.0;
+    if (k > 0) dphi = (sh.phi - x0_shape<true>(loiter, row[X0F_T * ld + k - 1]).phi) / dt;    // the neighbour's bank again: a one-off table
+    row[X0F_S * ld + k] = sh.s;        row[X0F_C * ld + k] = sh.c;       row[X0F_VA * ld + k] = sh.Va;
+    row[X0F_CHI0 * ld + k] = sh.chi0;  row[X0F_GAM * ld + k] = sh.gam;   row[X0F_NMAG * ld + k] = sh.nmag;
+    row[X0F_PHI * ld + k] = sh.phi;    row[X0F_DOT * ld + k] = sh.dot;   row[X0F_DPHI * ld + k] = dphi;
+}
 
 template <typename T, int MISSION>
-__global__ __launch_bounds__(X0_NODES) void x0_kernel(const FgArgs a, const double *tgrid)
+__global__ __launch_bounds__(X0_NODES) void x0_kernel(const FgArgs a, const double *tab)
 {
     constexpr double kPi = 3.14159265358979323846;
-    __shared__ double raw_s[X0_NODES + 1], chi_s[X0_NODES + 1], phi_s[X0_NODES + 1], CL_s[X0_NODES + 1];   // [0] = the node before the pass
+    __shared__ double raw_s[X0_NODES + 1], chi_s[X0_NODES + 1], CL_s[X0_NODES + 1];   // [0] = the node before the pass
     __shared__ int wraps_s[X0_NODES / TILE];
     __shared__ int redo_s;
     __shared__ T img[X0_NODES * NI];
@@ -1443,9 +1502,10 @@ __global__ __launch_bounds__(X0_NODES) void x0_kernel(const FgArgs a, const doub
     T *x = static_cast<T *>(const_cast<void *>(a.X)) + (long)b * a.ldx;
     const double dt = (loiter ? 20.0 : 10.0) / N;
     const double cd = tr.cchi, sd = tr.schi;
-    const double *tg = tgrid + (loiter ? 0 : N + 1);
+    const long ld = N + 1;
+    const double *row = tab + (loiter ? 0 : (long)X0_FIELDS * ld);
     int wraps_before = 0;                       // 2 pi multiples the node before the pass carries (every thread keeps its copy)
-    if (tid == 0) { raw_s[0] = 0.0; chi_s[0] = 0.0; phi_s[0] = 0.0; CL_s[0] = 0.0; redo_s = 0; x[0] = T(dt); }
+    if (tid == 0) { raw_s[0] = 0.0; chi_s[0] = 0.0; CL_s[0] = 0.0; redo_s = 0; x[0] = T(dt); }
     double dphi = 0.0, dCL = 0.0;
     for (int k0 = 0; k0 <= N; k0 += X0_NODES) {
         const int k = k0 + tid;
@@ -1453,8 +1513,13 @@ __global__ __launch_bounds__(X0_NODES) void x0_kernel(const FgArgs a, const doub
         const bool act = tid < cnt;
         X0Node o{};
         if (act) {
-            o = x0_node<true>(loiter, tg[k], tr, ac, cd, sd);
-            raw_s[tid + 1] = o.chi_raw; phi_s[tid + 1] = o.phi; CL_s[tid + 1] = o.CL;
+            X0Shape sh;
+            sh.s = row[X0F_S * ld + k];        sh.c = row[X0F_C * ld + k];       sh.Va = row[X0F_VA * ld + k];
+            sh.chi0 = row[X0F_CHI0 * ld + k];  sh.gam = row[X0F_GAM * ld + k];   sh.nmag = row[X0F_NMAG * ld + k];
+            sh.phi = row[X0F_PHI * ld + k];    sh.dot = row[X0F_DOT * ld + k];
+            dphi = row[X0F_DPHI * ld + k];
+            o = x0_finish(loiter, row[X0F_T * ld + k], sh, tr, ac, cd, sd);
+            raw_s[tid + 1] = o.chi_raw; CL_s[tid + 1] = o.CL;
         }
         __syncthreads();
         // wraps up to and including this node: +1 where the raw course falls by more than pi, -1 where it rises by more
@@ -1476,7 +1541,10 @@ __global__ __launch_bounds__(X0_NODES) void x0_kernel(const FgArgs a, const doub
         for (int q = 0; q < X0_NODES / TILE; q++) pass_wraps += wraps_s[q];
         m += wraps_before;
         double chi = o.chi_raw;
-        if (m != 0) chi = chi + 2.0 * kPi * (double)m;
+        if (m != 0) {
+#pragma clang fp contract(off)
+            chi = chi + 2.0 * kPi * (double)m;
+        }
         if (act) chi_s[tid + 1] = chi;
         __syncthreads();
         // the reference's own step against the neighbour's guess
@@ -1490,7 +1558,6 @@ __global__ __launch_bounds__(X0_NODES) void x0_kernel(const FgArgs a, const doub
             if (act) chi = chi_s[tid + 1];
         }
         if (act) {
-            dphi = k ? (o.phi - phi_s[tid]) / dt : 0.0;
             dCL = k ? (o.CL - CL_s[tid]) / dt : 0.0;
             T *nd = img + NI * tid;
             nd[0] = T(o.p[0]); nd[1] = T(o.p[1]); nd[2] = T(o.p[2]);
@@ -1518,11 +1585,11 @@ __global__ __launch_bounds__(X0_NODES) void x0_kernel(const FgArgs a, const doub
             if (tid < E - done_) dst[done_ + tid] = img[done_ + tid];
         }
         // the last node of this pass is "the node before" of the next
-        const double craw = raw_s[cnt], cchi = chi_s[cnt], cphi = phi_s[cnt], cCL = CL_s[cnt];
+        const double craw = raw_s[cnt], cchi = chi_s[cnt], cCL = CL_s[cnt];
         // a redone pass may have left the guess's wrap count behind: take it from the continuous course itself
         wraps_before = redo_s ? (int)rint((cchi - craw) / (2.0 * kPi)) : wraps_before + pass_wraps;
         __syncthreads();
-        if (tid == 0) { raw_s[0] = craw; chi_s[0] = cchi; phi_s[0] = cphi; CL_s[0] = cCL; redo_s = 0; }
+        if (tid == 0) { raw_s[0] = craw; chi_s[0] = cchi; CL_s[0] = cCL; redo_s = 0; }
         if (loiter && k == N) {                 // src/problemS10.cpp:210-211: node 0's rates are overwritten by node N's
             // (the stores of node 0's row left before a barrier of this workgroup, so these land after them)
             x[9] = T(dphi);
@@ -1659,10 +1726,19 @@ hipError_t launch_sum(const void *v, int B, int dtype, double *out, hipStream_t 
     return hipGetLastError();
 }
 
-hipError_t launch_x0(const FgArgs &a, int mission, int dtype, const double *tgrid, hipStream_t s)
+hipError_t launch_x0_table(double *tab, int N, int mission, hipStream_t s)
+{
+    const dim3 block(X0_NODES), grid((N + 1 + X0_NODES - 1) / X0_NODES, mission == MISSION_MIXED ? 2 : 1);
+    if (mission == MISSION_S10)     hipLaunchKernelGGL(x0_table_kernel<MISSION_S10>, grid, block, 0, s, tab, N);
+    else if (mission == MISSION_G7) hipLaunchKernelGGL(x0_table_kernel<MISSION_G7>, grid, block, 0, s, tab, N);
+    else                            hipLaunchKernelGGL(x0_table_kernel<MISSION_MIXED>, grid, block, 0, s, tab, N);
+    return hipGetLastError();
+}
+
+hipError_t launch_x0(const FgArgs &a, int mission, int dtype, const double *tab, hipStream_t s)
 {
     if (a.B <= 0) return hipSuccess;
-    if (!tgrid) {       // the serial reference form (measurements, bitwise A/B)
+    if (!tab) {       // the serial reference form (measurements, bitwise A/B)
         const dim3 grid((a.B + 63) / 64), block(64);
         if (dtype == 0) {
             if (mission == MISSION_S10)     hipLaunchKernelGGL((x0_serial_kernel<double, MISSION_S10>), grid, block, 0, s, a);
@@ -1677,13 +1753,13 @@ hipError_t launch_x0(const FgArgs &a, int mission, int dtype, const double *tgri
     }
     const dim3 grid(a.B), block(X0_NODES);
     if (dtype == 0) {
-        if (mission == MISSION_S10)     hipLaunchKernelGGL((x0_kernel<double, MISSION_S10>), grid, block, 0, s, a, tgrid);
-        else if (mission == MISSION_G7) hipLaunchKernelGGL((x0_kernel<double, MISSION_G7>), grid, block, 0, s, a, tgrid);
-        else                            hipLaunchKernelGGL((x0_kernel<double, MISSION_MIXED>), grid, block, 0, s, a, tgrid);
+        if (mission == MISSION_S10)     hipLaunchKernelGGL((x0_kernel<double, MISSION_S10>), grid, block, 0, s, a, tab);
+        else if (mission == MISSION_G7) hipLaunchKernelGGL((x0_kernel<double, MISSION_G7>), grid, block, 0, s, a, tab);
+        else                            hipLaunchKernelGGL((x0_kernel<double, MISSION_MIXED>), grid, block, 0, s, a, tab);
     } else {
-        if (mission == MISSION_S10)     hipLaunchKernelGGL((x0_kernel<float, MISSION_S10>), grid, block, 0, s, a, tgrid);
-        else if (mission == MISSION_G7) hipLaunchKernelGGL((x0_kernel<float, MISSION_G7>), grid, block, 0, s, a, tgrid);
-        else                            hipLaunchKernelGGL((x0_kernel<float, MISSION_MIXED>), grid, block, 0, s, a, tgrid);
+        if (mission == MISSION_S10)     hipLaunchKernelGGL((x0_kernel<float, MISSION_S10>), grid, block, 0, s, a, tab);
+        else if (mission == MISSION_G7) hipLaunchKernelGGL((x0_kernel<float, MISSION_G7>), grid, block, 0, s, a, tab);
+        else                            hipLaunchKernelGGL((x0_kernel<float, MISSION_MIXED>), grid, block, 0, s, a, tab);
     }
     return hipGetLastError();
 }

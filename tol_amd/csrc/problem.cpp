@@ -529,17 +529,22 @@ void batch::x0_device(int B, void *dX, long ldx, hipStream_t stream)
     a.X = dX; a.ldx = ldx; a.traj = d_traj_; a.B = B;
     const bool serial = std::getenv("TOLFG_X0_SERIAL") != nullptr;      // measurement / bitwise A/B: the serial reference form
     if (!serial && !d_tgrid_) {
-        // node times exactly as InitialCond forms them: t = t + dt from 0 (ref: src/problemS10.cpp:60-64)
+        // node times exactly as InitialCond forms them: t = t + dt from 0 (ref: src/problemS10.cpp:60-64); the rest of
+        // the table (what a node's row holds for every trajectory of a mission alike) is computed on the device from
+        // them, once per batch object
         const int N = sz_.N;
-        std::vector<double> tg(2 * (size_t)(N + 1));
+        const size_t ld = (size_t)N + 1;
+        std::vector<double> tg(2 * (size_t)X0_FIELDS * ld, 0.0);
         for (int m = 0; m < 2; ++m) {
             const double dt = (m == 0 ? 20.0 : 10.0) / N;
             double t = 0.0;
-            for (int k = 0; k <= N; ++k, t = t + dt) tg[(size_t)m * (N + 1) + k] = t;
+            for (int k = 0; k <= N; ++k, t = t + dt) tg[(size_t)m * X0_FIELDS * ld + k] = t;
         }
         check(hipSetDevice(device_), "hipSetDevice");
-        check(hipMalloc(reinterpret_cast<void **>(&d_tgrid_), sizeof(double) * tg.size()), "hipMalloc(tgrid)");
-        check(hipMemcpy(d_tgrid_, tg.data(), sizeof(double) * tg.size(), hipMemcpyHostToDevice), "hipMemcpy(tgrid)");
+        check(hipMalloc(reinterpret_cast<void **>(&d_tgrid_), sizeof(double) * tg.size()), "hipMalloc(x0 table)");
+        check(hipMemcpy(d_tgrid_, tg.data(), sizeof(double) * tg.size(), hipMemcpyHostToDevice), "hipMemcpy(x0 table)");
+        check(launch_x0_table(d_tgrid_, N, mission_, stream), "launch x0 table");
+        check(hipStreamSynchronize(stream), "x0 table");      // later calls may come on other streams
     }
     check(launch_x0(a, mission_, dtype_, serial ? nullptr : d_tgrid_, stream), "launch x0");
 }

@@ -112,7 +112,7 @@ private:
     std::vector<hipEvent_t> ev_;
     size_t ev_used_ = 0;
     void *d_grid_ = nullptr;
-    double *d_tgrid_ = nullptr;         // node times of the initial guess, [2][N+1] (x0_device)
+    double *d_tgrid_ = nullptr;         // the initial guess's per-(mission, node) table, [2][X0_FIELDS][N+1]: field 0 = node times (x0_device)
     std::vector<double> grid_host_;
     double *d_partial_ = nullptr;
     long partial_cap_ = 0;
