@@ -114,6 +114,7 @@ void *device_alloc(int device, size_t bytes)
         const long k = std::atol(e);
         if (k >= 64 && k <= (1L << 20) && (k & (k - 1)) == 0) kPlacedChunk = (size_t)k << 10;
     }
+    DeviceGuardLocal guard;
     check(hipSetDevice(device), "hipSetDevice");
     DeviceBlock blk;
     blk.device = device;
