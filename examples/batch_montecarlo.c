@@ -45,8 +45,8 @@ int main(int argc, char **argv)
     CK(hipMalloc((void **)&dX, sizeof(double) * B * ldx));
     CK(hipMalloc((void **)&dF, sizeof(double) * B * ldf));
     /* G, nine tenths of what a launch writes, from the library: where it lands in HBM decides how fast a launch beyond the cache runs
-       (include/tolfg.h, "Where the outputs live"); up to 6 candidates are timed, the best kept */
-    TK(tolfg_batch_alloc_outputs(bt, B, 6, (void **)&dG, &ldg, NULL, NULL));
+       (include/tolfg.h, "Where the outputs live"); up to 12 candidates are timed, the best kept */
+    TK(tolfg_batch_alloc_outputs(bt, B, 12, (void **)&dG, &ldg, NULL, NULL));
     CK(hipMalloc((void **)&dObj, sizeof(double) * B));
     TK(tolfg_batch_x0_device(bt, B, dX, ldx, NULL));                       /* initial guess, on the device */
     TK(tolfg_batch_eval(bt, B, dX, ldx, dF, ldf, dG, ldg, NULL, 1, 1, dObj, NULL));

@@ -297,7 +297,7 @@ int  tolfg_batch_objectives(tolfg_batch *b, int B, const void *dF, long ldf, voi
  *   tolfg_device_alloc / tolfg_device_free: device memory in that form (falls back to hipMalloc where the runtime has no
  *     virtual-memory support) -- for X, F, G or anything else; a pointer from it is an ordinary device pointer;
  *   tolfg_batch_alloc_outputs: the G buffer of B trajectories ([B][*ldg] elements of the batch dtype, *ldg = the row length
- *     rounded up to 16 bytes), PLACED for this batch's launch: up to `tries` candidates (1..8; the Python layer and tolfg_multi take 6) from
+ *     rounded up to 16 bytes), PLACED for this batch's launch: up to `tries` candidates (1..16, and never more than fit side by side into half of the free device memory; the Python layer and tolfg_multi take 12: ~0.05 s each) from
  *     tolfg_device_alloc, held side by side, each timed with the bare store loop of the launch's own shape
  *     (tolfg_batch_set_store_shape); the search ends early once a candidate is 18 % faster than the slowest seen (fast and slow
  *     class are ~20 % apart); the fastest is kept, the rest freed.  probe_us (NULL or [tries]) receives the candidates' times in us, *tried (NULL or int)

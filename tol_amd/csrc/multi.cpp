@@ -301,7 +301,7 @@ void multi::set_trajectories(long total, const tolfg_traj *trajs)
         // G, the bulk of what a launch writes, comes placed for this shard's launch (problem.h: alloc_outputs)
         if (B > 0) {
             long ldg = 0;
-            p.dG = p.b->alloc_outputs((int)B, 6, &ldg, nullptr, nullptr);
+            p.dG = p.b->alloc_outputs((int)B, 12, &ldg, nullptr, nullptr);
             if (ldg != ldg_) throw std::logic_error("tolfg_multi: row stride of the placed G buffer");
         } else {
             p.dG = device_alloc(p.device, elem() * rows * ldg_);

@@ -587,7 +587,20 @@ void *batch::alloc_outputs(int B, int tries, long *ldg_out, double *probe_us, in
     const double out_bytes = (double)elem_size() * B * ((double)sz_.neF + sz_.neG);
     const LaunchPlan lp = plan_launch(LaunchShape{B, sz_.N, dtype_, args_.pattern, mission_, 1, out_bytes});
     // placement matters to launches that stream beyond the cache (non-temporal form); the others take what they get
-    const int n = (tries < 1 || !lp.nt_stores || lp.single) ? 1 : (tries > 8 ? 8 : tries);
+    // measurement: TOLFG_PLACE_CAP moves the cap on the candidates (16), TOLFG_PLACE_EARLY sets the early-accept ratio (0.82; 0 = try them all)
+    int cap = 16;
+    double early = 0.82;
+    if (const char *e = std::getenv("TOLFG_PLACE_CAP")) { const int c = std::atoi(e); if (c >= 1 && c <= 64) cap = c; }
+    if (const char *e = std::getenv("TOLFG_PLACE_EARLY")) { const double r = std::atof(e); if (r >= 0.0 && r < 1.0) early = r; }
+    int n = (tries < 1 || !lp.nt_stores || lp.single) ? 1 : (tries > cap ? cap : tries);
+    if (n > 1) {      // the candidates are held side by side: never more than half of the device's free memory
+        size_t free_b = 0, total_b = 0;
+        check(hipSetDevice(device_), "hipSetDevice");
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            const size_t fit = (free_b / 2) / bytes;
+            if ((size_t)n > fit) n = fit < 1 ? 1 : (int)fit;
+        } else clear_errors();
+    }
     if (probe_us) for (int i = 0; i < (tries > 0 ? tries : 1); ++i) probe_us[i] = 0.0;
     if (tried) *tried = n;
     if (n == 1) return device_alloc(device_, bytes);
@@ -632,7 +645,7 @@ void *batch::alloc_outputs(int B, int tries, long *ldg_out, double *probe_us, in
             if (us > slowest) slowest = us;
             if (fastest == 0.0 || us < fastest) fastest = us;
             if (tried) *tried = i + 1;
-            if (fastest < 0.82 * slowest) break;
+            if (fastest < early * slowest) break;
         }
     } catch (...) {
         store_shape_ = was_store_shape;

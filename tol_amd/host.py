@@ -345,7 +345,7 @@ class Batch:
         import torch
         return torch.float64 if self.dtype == "f64" else torch.float32
 
-    def alloc(self, B=None, pad=None, placed=None, tries=6):
+    def alloc(self, B=None, pad=None, placed=None, tries=12):
         """X, F, G device tensors with row strides padded to `pad` elements (default: 16 bytes).
         placed (default: True when the trajectories are described and pad is the default): G comes from the library's
         placement-probing allocator (tolfg_batch_alloc_outputs: an address range backed by 2 MiB physical chunks, the best
@@ -373,7 +373,7 @@ class Batch:
             G = torch.zeros((B, up(self.neG)), dtype=dt, device=dev)
         return X, F, G
 
-    def alloc_outputs(self, B, tries=6):
+    def alloc_outputs(self, B, tries=12):
         """The G tensor [B][ldg] from tolfg_batch_alloc_outputs (uninitialised); self.placement records the probe."""
         import torch
         ptr, ldg, tried = C.c_void_p(), C.c_long(), C.c_int()
