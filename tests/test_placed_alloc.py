@@ -67,7 +67,7 @@ def test_outputs_in_a_placed_buffer_match_the_oracle(tolfg, oracle, mission, dty
         pr = bt.placement["probe_us"]
         assert len(pr) == bt.placement["candidates"] and all(p > 0 for p in pr)
         # the search stops early only on a candidate 18 % faster than the slowest seen
-        assert len(pr) == 6 or min(pr) < 0.82 * max(pr)
+        assert len(pr) == 12 or min(pr) < 0.82 * max(pr)
     assert dG.shape[0] == B and dG.shape[1] >= bt.neG and dG.data_ptr() % (2 << 20) == 0
     bt.x0_device(dX)
     bt.eval(dX, dF, dG)
