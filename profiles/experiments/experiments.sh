@@ -948,6 +948,23 @@ done
 done
 find "$OUT" -name "*.csv" -size +2M -delete
 ;;
+r04_alloc_probe)
+# One allocation probe per call (tools/alloc_probe.py ... alloc_probe8.py; $2 = 1 ... 8, further arguments are the probe's own, e.g. "3 order"):
+# where the output buffer lands decides the class the launch runs in (profiles/r04_allocation_classes.md).
+set -u
+n=${2:-7}
+shift; shift || true
+tool=tools/alloc_probe$([ "$n" = 1 ] || echo "$n").py
+mkdir -p gpurun_out/r04_alloc
+timeout -k 10 400 python3 "$tool" "$@" 2>&1 | grep -v amdgpu.ids | tee "gpurun_out/r04_alloc/probe_$n.txt"
+;;
+r04_x0_time)
+# Initial guesses on the device: serial walk vs the table-driven node-parallel kernel, and the bitwise test (profiles/r04_x0_kernel.md).
+set -u
+mkdir -p gpurun_out/r04_x0
+timeout -k 10 240 python3 -m pytest tests/test_device_setup.py -m gpu -q 2>&1 | tail -2
+timeout -k 10 200 python3 tools/x0_time.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r04_x0/x0_time.txt
+;;
 list|*)
 cat <<'LIST'
 r02a                   round-2 experiment A (one gpurun call): write-stream shapes, tile size x cap x fused sweep, callback trace  [r02_write_shapes.md]
@@ -1018,6 +1035,8 @@ r04_callback_tiles     the callback (B = 1) as one workgroup vs tile workgroups 
 r04_incache_counters   what binds launches whose outputs fit the cache: rocprofv3 stats + one counter per pass, B = 1024 / 2048  [r04_incache_counters.md]
 r04_fp32_traffic       where the extra 4.6 % of HBM bytes of the fp32 launches come from: write / read request counters, mixed / S10 / G7 / fp64  [r04_fp32_traffic.md]
 r04_align_counters     write requests with the slab streams cut to 64-byte boundaries (r04_stream_align64.patch applied) vs the 16-byte form  [r04_fp32_traffic.md]
+r04_alloc_probe N      one of the allocation probes tools/alloc_probe.py ... alloc_probe8.py (N = 1 ... 8; further arguments are the probe's own)  [r04_allocation_classes.md]
+r04_x0_time            initial guesses on the device: serial walk vs the table-driven node-parallel kernel, bitwise test first  [r04_x0_kernel.md]
 LIST
 ;;
 esac
