@@ -648,6 +648,9 @@ def main():
     configs = None
     if not args.no_configs:
         configs = stated_config_records(tol_amd, job, args.x_buffers, keep=keep)      # every rank takes part
+    x_cached = None
+    if world == 1 and not args.no_configs and keep:
+        x_cached = same_x_record(torch, next(iter(keep.values())), r["B"], args.ts, min(args.steps, 100))
     for held in keep.values():
         held[0].close()
     keep.clear()
@@ -726,11 +729,29 @@ def main():
                 line["s10_batch_4096"] = s4096
                 line["next_compact_pattern"] = compact_side_run(tol_amd, torch, side, 4096, local)
                 line["two_batches_two_streams"] = two_streams_record(tol_amd, torch, side, 4096, local)
+                if x_cached is not None:
+                    line["headline_same_x_every_step"] = x_cached
         print(json.dumps(line), flush=True)
 
     if world > 1:
         job.barrier()
         dist.destroy_process_group()
+
+
+def same_x_record(torch, held, B, ts, steps):
+    """Side record, not the headline: the headline's batch on the headline's buffers with the SAME X buffer every step, so that
+    the x windows (145 MB at B = 8192, fp64) come from the 256 MiB Infinity Cache instead of HBM -- what an evaluation sees
+    whose x was written just before it.  The headline itself rotates x_buffers X buffers so that x comes from HBM
+    (BASELINE: inputs resident in HBM).  profiles/r04_allocation_classes.md: with x in the cache the evaluation hardly
+    depends on the placement class of the output buffer."""
+    bt, dXs, dF, dG = held
+    obj = torch.empty(B, dtype=dF.dtype, device=dF.device)
+    wall, kms, _, _ = timed_evals(bt, torch, dXs[:1], dF, dG, B, steps, 5, obj)
+    alg = bt.algorithmic_bytes(B)
+    gbs = alg / (kms * 1e-3) / 1e9
+    return {"workload": "the headline's batch and buffers, the same X buffer every step (x from the Infinity Cache)", "steps": steps,
+            "kernel_ms": kms, "node_evals_per_s": B * ts * steps / wall, "achieved_GBs": gbs, "frac_of_hbm_peak": gbs / HBM_PEAK_GBS,
+            "note": "frac over the same algorithmic bytes as the headline, of which the x bytes did not come from HBM here"}
 
 
 def compact_side_run(tol_amd, torch, args, B, device, steps=50):

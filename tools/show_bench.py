@@ -38,3 +38,7 @@ for key in ("s10_batch_4096", "headline_shape_larger_batch"):
     if key in d:
         c = d[key]
         print("  %s: evaluation %.1f us = %.3f of peak, whole step %.4g node-evals/s" % (c["workload"], c["eval_us"], c["frac_of_hbm_peak"], c["node_evals_per_s"]))
+if "headline_same_x_every_step" in d:
+    c = d["headline_same_x_every_step"]
+    print("  side: the headline with the same X buffer every step (x from the Infinity Cache): %.1f us per launch = %.3f of peak over the same algorithmic bytes"
+          % (1e3 * c["kernel_ms"], c["frac_of_hbm_peak"]))
