@@ -358,12 +358,15 @@ def single_gpu_records(tol_amd, torch, device):
 class Job:
     """The process group of this run (one rank per GPU) and the one collective the path has."""
 
-    def __init__(self, torch, dist, world, rank, local, backend):
+    def __init__(self, torch, dist, world, rank, local, backend, collective=None):
         self.torch, self.dist, self.world, self.rank, self.local, self.backend = torch, dist, world, rank, local, backend
+        # whether the collectives of the N > 1 path are issued: always with several ranks; with ONE rank only under
+        # --single-rank-collectives (a rehearsal of the RCCL calls on a box with one GPU)
+        self.collective = (world > 1) if collective is None else collective
 
     def barrier(self):
         self.torch.cuda.synchronize()
-        if self.world > 1:
+        if self.collective:
             if self.backend == "nccl":
                 self.dist.barrier(device_ids=[self.local])
             else:
@@ -372,7 +375,7 @@ class Job:
 
     def max_over_ranks(self, values):
         t = self.torch.tensor(values, dtype=self.torch.float64, device="cuda")
-        if self.world > 1:
+        if self.collective:
             if self.backend == "nccl":
                 self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
             else:
@@ -385,11 +388,12 @@ class Job:
 def sharded_run(tol_amd, job, mission, aircraft, ts, dtype, pattern, per_gpu, global_batch, steps, warmup, x_buffers, instrumented=True,
                 keep=None):
     """Exactly `steps` steps of one workload over the job's ranks between two barriers.  A step = this rank's shard in ONE
-    launch (F, G and the objectives) + the all-gather of the objectives (N > 1; asynchronous, double-buffered, so it
+    launch (F, G and the objectives) + the all-gather of the objectives (N > 1; asynchronous, four buffers in rotation, so it
     overlaps the next step's launch).  per_gpu > 0: weak scaling, that many trajectories per rank; else global_batch
     trajectories split by shard_bounds (strong scaling).  Returns the timings as maxima over the ranks."""
     from tol_amd.distributed import shard_bounds
     torch, dist, world, rank = job.torch, job.dist, job.world, job.rank
+    coll = job.collective
     if per_gpu > 0:
         B, first, total, scaling = per_gpu, rank * per_gpu, per_gpu * world, "weak"
         Bmax = B
@@ -410,29 +414,38 @@ def sharded_run(tol_amd, job, mission, aircraft, ts, dtype, pattern, per_gpu, gl
         dXs, dF, dG = make_inputs(bt, torch, max(B, 1), first, x_buffers)
         if keep is not None:
             keep[key] = (bt, dXs, dF, dG)
-    obj = [torch.zeros(Bmax, dtype=dF.dtype, device=dF.device) for _ in range(2)]
+    # Objective buffers in rotation: the launch of step i writes obj[i % NOBJ] and must wait for the gather that last read it,
+    # the one of step i - NOBJ.  With two buffers that wait was on the critical path (measured with one RCCL rank: 303 instead
+    # of 277 us per step): a launch keeps every CU's LDS and wave slots booked until its last tiles, so the gather's kernel,
+    # queued behind launch i-2, only gets onto the chip in the tail of launch i-1 -- and launch i then stood waiting for it.
+    # Four buffers (and a high-priority stream for RCCL, main()) take the gather off that path.
+    NOBJ = 4
+    obj = [torch.zeros(Bmax, dtype=dF.dtype, device=dF.device) for _ in range(NOBJ)]
     gdev = dF.device if job.backend == "nccl" else torch.device("cpu")
-    allobj = [torch.empty(Bmax * world, dtype=dF.dtype, device=gdev) for _ in range(2)] if world > 1 else None
-    pending = [None, None]
+    allobj = [torch.empty(Bmax * world, dtype=dF.dtype, device=gdev) for _ in range(NOBJ)] if coll else None
+    pending = [None] * NOBJ
 
     def step(i):
-        s = i & 1
-        if world > 1 and pending[s] is not None:
-            pending[s].wait()                      # buffer reuse: the gather of step i-2 must be done
+        s = i % NOBJ
+        if coll and pending[s] is not None:
+            # buffer reuse: the gather of step i - NOBJ must be done.  It normally is, long ago: then nothing is put into the
+            # launch stream (a stream-wait marker between two launches costs the dependent launch a few microseconds)
+            if not pending[s].is_completed():
+                pending[s].wait()
         if B > 0:
             bt.eval(dXs[i % len(dXs)], dF, dG, obj=obj[s], B=B)     # the finalizing waves also write the objectives, contiguous
-        if world > 1:
+        if coll:
             src = obj[s] if job.backend == "nccl" else obj[s].cpu()
             pending[s] = dist.all_gather_into_tensor(allobj[s], src, async_op=True)
 
     def fence():
-        for s in (0, 1):
+        for s in range(NOBJ):
             if pending[s] is not None:
                 pending[s].wait()
                 pending[s] = None
         job.barrier()
 
-    warm_run = settle(step, fence, warmup, job.max_over_ranks if world > 1 else None)
+    warm_run = settle(step, fence, warmup, job.max_over_ranks if coll else None)
     # The timed region: exactly `steps` steps between two barriers.  Two HIP events on the launch stream bracket the
     # launches (before the first, after the last): their distance / steps is the average time per launch, the ~2 us
     # between dependent launches included -- an upper bound of the kernel's own duration, taken without instrumenting it.
@@ -446,16 +459,16 @@ def sharded_run(tol_amd, job, mission, aircraft, ts, dtype, pattern, per_gpu, gl
     fence()
     elapsed = time.perf_counter() - t0
     kern_ms = ev0.elapsed_time(ev1) / steps
-    last = (steps - 1) & 1
+    last = (steps - 1) % NOBJ
     assert B == 0 or torch.isfinite(obj[last][:B]).all(), "non-finite objective"
-    if world > 1:      # every rank's shard arrived in place, in global trajectory order
+    if coll:      # every rank's shard arrived in place, in global trajectory order
         mine = obj[last].to(allobj[last].device)
         assert torch.equal(allobj[last][rank * Bmax:(rank + 1) * Bmax], mine), "gathered objectives are out of order"
     out = {"B": B, "total": total, "scaling": scaling, "x_buffers": len(dXs), "buffers_reused": reused,
            "placement": getattr(bt, "placement", None)}
     # the gather alone (N > 1): synchronous all-gathers of the same buffers, nothing else in flight
     gather_us = 0.0
-    if world > 1:
+    if coll:
         reps = 50
         src = obj[0] if job.backend == "nccl" else obj[0].cpu()
         for _ in range(5):
@@ -595,6 +608,9 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N > 1: nccl = RCCL over xGMI; gloo (objectives staged through host "
                          "memory) only rehearses the multi-rank step loop, e.g. several ranks sharing one GPU")
+    ap.add_argument("--single-rank-collectives", action="store_true",
+                    help="rehearsal on a box with one GPU: a process group of ONE rank on --backend, and every collective of the "
+                         "N > 1 path is issued (barrier, all-reduce of the timings, the asynchronous all-gather of the objectives)")
     args = ap.parse_args()
 
     MIN_WARM_S, CALIBRATE = max(args.min_warm_seconds, 0.0), not args.no_calibration
@@ -602,6 +618,13 @@ def main():
         # started as a plain command: nothing has touched a GPU yet, so the ranks are started from here as a CHILD
         # (never an exec) and this process only relays rank 0's line and the child's exit code
         sys.exit(spawn_ranks(args.gpus))
+
+    # This process's stdout carries ONE line, the result.  Libraries write there too -- RCCL prints a version banner
+    # ("RCCL version : ...", four lines) on stdout when its first communicator comes up -- so file descriptor 1 is pointed
+    # at stderr for everything else, and the result line goes out through a private copy of the original descriptor.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
 
     import torch
     import torch.distributed as dist
@@ -617,15 +640,31 @@ def main():
     if args.backend == "gloo":
         local = local % max(ndev, 1)               # rehearsal: ranks may share a GPU
     torch.cuda.set_device(local)
-    if world > 1:
+    coll = world > 1 or args.single_rank_collectives
+    if coll:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:       # started as a plain command: the rendezvous of a world of one
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ.setdefault("MASTER_PORT", str(sk.getsockname()[1]))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             # eager communicator creation on this rank's GPU (RCCL over xGMI) and a first collective outside any
             # timing (RCCL builds its rings lazily).  A failure here is fatal: a scaling point measured over a
             # host-staged fallback would not be "RCCL over xGMI"; gloo is only ever chosen with --backend gloo.
             try:
+                # RCCL's kernels on a high-priority stream: a collective queued behind a launch that has every CU booked gets
+                # onto the chip when the first wave slots free up, not when the launch's backlog of tiles is through
+                opts = None
                 try:
-                    dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+                    opts = dist.ProcessGroupNCCL.Options()
+                    opts.is_high_priority_stream = True
+                except Exception:      # noqa: BLE001
+                    opts = None
+                try:
+                    dist.init_process_group("nccl", device_id=torch.device("cuda", local), pg_options=opts)
                 except TypeError:
                     dist.init_process_group("nccl")
                 probe = torch.ones(1, device="cuda")
@@ -639,7 +678,7 @@ def main():
                 os._exit(3)
         else:
             dist.init_process_group("gloo")
-    job = Job(torch, dist, world, rank, local, args.backend)
+    job = Job(torch, dist, world, rank, local, args.backend, collective=coll)
 
     aircraft = AIRCRAFT5 if args.mission == "mixed" else (args.aircraft,)
     keep = {}        # the headline's batch and buffers: re-used by a stated config of the same workload (one GPU: configs[4] fp64)
@@ -673,7 +712,9 @@ def main():
                     traffic_source = "profiles/traffic_latest.json (replayed: PMC passes of " + str(tj.get("source", "tools/profile_gpu.sh")) + ", not measured in this run)"
             except (OSError, ValueError):
                 traffic = None
-        backend = "none (single GPU)" if world == 1 else ("rccl" if args.backend == "nccl" else "gloo (host-staged rehearsal)")
+        backend = "none (single GPU)" if not coll else ("rccl" if args.backend == "nccl" else "gloo (host-staged rehearsal)")
+        if coll and world == 1:
+            backend += ", ONE rank: a rehearsal of the collectives (--single-rank-collectives)"
         if args.mission == "mixed":
             what = (f"BASELINE configs[4]: mixed problemG7 + problemS10 batch (mission = b mod 2), all five aircraft .param files "
                     f"(b mod 5), ts={args.ts}, {args.dtype}")
@@ -711,7 +752,7 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "bytes_per_node": alg_bytes / max(B * args.ts, 1)},
         }
-        if world > 1:
+        if coll:
             line["gather_us"] = r["gather_us"]
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
@@ -731,9 +772,12 @@ def main():
                 line["two_batches_two_streams"] = two_streams_record(tol_amd, torch, side, 4096, local)
                 if x_cached is not None:
                     line["headline_same_x_every_step"] = x_cached
-        print(json.dumps(line), flush=True)
+        sys.stdout.flush()
+        data = (json.dumps(line) + "\n").encode()
+        while data:
+            data = data[os.write(result_fd, data):]
 
-    if world > 1:
+    if coll:
         job.barrier()
         dist.destroy_process_group()
 

@@ -36,3 +36,21 @@ def test_plain_command_with_two_ranks_prints_one_line(tmp_path):
     assert line["config"]["global_batch"] == 2 * line["config"]["batch_per_gpu"]
     assert line["value"] > 0 and 0 < line["roofline"]["frac"] < 1 and line["gather_us"] > 0
     assert sorted((r["config"], r["dtype"], r["n_gpus"]) for r in line["configs"]) == [(3, "f64", 2), (4, "f32", 2), (4, "f64", 2)]
+
+
+@pytest.mark.gpu
+def test_the_rccl_calls_of_the_multi_rank_path_run_with_one_rank():
+    """A box with one GPU cannot hold two RCCL ranks, but a process group of ONE rank on the nccl backend issues the same
+    calls as the N > 1 path on the same kinds of tensors: communicator creation on this GPU, barrier(device_ids), the
+    all-reduce (MAX) of the timings and warm-up counts, the asynchronous all-gather (buffers in rotation) of the objectives out
+    of the buffer the finalizing waves write.  bench.py --single-rank-collectives; the stated configs run sharded as well."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--single-rank-collectives", "--steps", "5", "--warmup", "2",
+                          "--batch", "2048", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 1 and "rccl" in line["backend"] and "ONE rank" in line["backend"]
+    assert line["value"] > 0 and 0 < line["roofline"]["frac"] < 1 and line["gather_us"] > 0
+    assert any(r.get("gather_us", 0) > 0 for r in line["configs"] if r["mode"] == "device-resident" and r["config"] in (3, 4))
