@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Soak: many evaluations back to back on rotating X buffers, every one checked bit for bit against the first evaluation of its X
+buffer (64-bit integer checksums of F, G and the objectives, taken on the device after every launch).  The kernel is deterministic
+-- fixed summation orders, no floating-point atomics -- so ANY difference is a race (arrival counters, polled partial slots,
+workspace reuse between launches)."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import tol_amd
+import bench as BN
+
+SECONDS = float(sys.argv[1]) if len(sys.argv) > 1 else 8.0
+SHAPES = [("S10", "f64", 1024, "reference"), ("mixed", "f64", 8192, "reference"), ("mixed", "f32", 2048, "reference"), ("S10", "f64", 4096, "compact"),
+          ("G7", "f64", 37, "reference"), ("mixed", "f32", 8192, "reference"), ("S10", "f64", 1, "reference")]
+bad_total = 0
+for mission, dtype, B, pattern in SHAPES:
+    air = BN.AIRCRAFT5 if mission == "mixed" else ("tempest",)
+    bt = tol_amd.Batch(mission, air, ts=200, dtype=dtype, pattern=pattern)
+    bt.set_trajectories(BN.make_trajectories(tol_amd, B, 0, mission, len(air)))
+    dXs, dF, dG = BN.make_inputs(bt, torch, B, 0, 4)
+    obj = torch.zeros(B, dtype=dF.dtype, device="cuda")
+    it = torch.int64 if dtype == "f64" else torch.int32
+
+    def checksum():
+        return torch.stack([dF.view(it).sum(dtype=torch.int64), dG.view(it).sum(dtype=torch.int64), obj.view(it).sum(dtype=torch.int64)])
+
+    ref = []
+    for x in dXs:
+        dF.zero_(); dG.zero_(); obj.zero_()
+        bt.eval(x, dF, dG, obj=obj, B=B)
+        ref.append(checksum())
+    ref = torch.stack(ref)
+    n, bad, t0 = 0, 0, time.perf_counter()
+    while time.perf_counter() - t0 < SECONDS:
+        sums = []
+        for i in range(200):
+            bt.eval(dXs[i % 4], dF, dG, obj=obj, B=B)
+            sums.append(checksum())
+        got = torch.stack(sums)
+        want = ref[torch.arange(200, device="cuda") % 4]
+        bad += int((got != want).any(dim=1).sum().item())
+        n += 200
+    print(f"{mission:5s} {dtype} B={B:5d} {pattern:9s}: {n} evaluations in {time.perf_counter() - t0:.1f} s, {bad} differ from the first evaluation of their X buffer", flush=True)
+    bad_total += bad
+    bt.close()
+sys.exit(1 if bad_total else 0)
