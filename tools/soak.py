@@ -46,4 +46,36 @@ for mission, dtype, B, pattern in SHAPES:
     print(f"{mission:5s} {dtype} B={B:5d} {pattern:9s}: {n} evaluations in {time.perf_counter() - t0:.1f} s, {bad} differ from the first evaluation of their X buffer", flush=True)
     bad_total += bad
     bt.close()
+
+# The SNOPT callback (host x -> host F, G), single trajectory: F and G are poisoned before every call, so an entry a call did
+# not write (a finalizing wave lost, a completion word seen before the data) shows as well as a wrong one.
+import numpy as np
+
+for ts, staged in ((200, False), (200, True), (2000, False)):
+    p = tol_amd.Problem("S10", "tempest", ts=ts, persistent_arrays=not staged)
+    x0 = p.x0()
+    rng = np.random.default_rng(5)
+    xs = [x0 * (1.0 + 0.03 * rng.uniform(-1, 1, x0.shape)) for _ in range(4)]
+    x, F, G = np.zeros(p.n), np.zeros(p.neF), np.zeros(p.neG)
+    refs = []
+    for xv in xs:
+        f, g, st = p.define_fg(xv)
+        assert st == 1
+        refs.append((f.copy(), g.copy()))
+    if not staged:
+        p.register_arrays(x, F, G)
+    n, bad, t0 = 0, 0, time.perf_counter()
+    while time.perf_counter() - t0 < SECONDS / 2:
+        for i in range(100):
+            np.copyto(x, xs[i % 4])
+            F.fill(np.nan); G.fill(np.nan)
+            _, _, st = p.define_fg(x, F=F, G=G)
+            if st != 1 or not (np.array_equal(F, refs[i % 4][0]) and np.array_equal(G, refs[i % 4][1])):
+                bad += 1
+        n += 100
+    print(f"callback S10 ts={ts:4d} {'staged  ' if staged else 'in place'}: {n} calls in {time.perf_counter() - t0:.1f} s, {bad} differ from the first call with their x", flush=True)
+    bad_total += bad
+    if not staged:
+        p.forget_arrays()
+    p.close()
 sys.exit(1 if bad_total else 0)
