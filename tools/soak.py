@@ -47,6 +47,41 @@ for mission, dtype, B, pattern in SHAPES:
     bad_total += bad
     bt.close()
 
+# Streams.  (a) one batch object evaluated on two streams in turn, same F / G: the library owns per-launch workspace and orders a
+# launch behind the previous one when the stream changes (include/tolfg.h, "Stream contract"); (b) two batch objects, each on
+# its own stream with its own buffers, in flight together.
+for label in ("one batch, two streams in turn", "two batches, two streams, in flight together"):
+    B = 2048
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    sets = []
+    for k in range(1 if label.startswith("one") else 2):
+        bt = tol_amd.Batch("mixed", BN.AIRCRAFT5, ts=200, dtype="f64")
+        bt.set_trajectories(BN.make_trajectories(tol_amd, B, 0, "mixed", 5))
+        dXs, dF, dG = BN.make_inputs(bt, torch, B, 0, 4)
+        obj = torch.zeros(B, dtype=dF.dtype, device="cuda")
+        ref = []
+        for x in dXs:
+            bt.eval(x, dF, dG, obj=obj, B=B)
+            ref.append(torch.stack([dF.view(torch.int64).sum(), dG.view(torch.int64).sum(), obj.view(torch.int64).sum()]))
+        sets.append((bt, dXs, dF, dG, obj, torch.stack(ref)))
+    torch.cuda.synchronize()
+    n, bad, t0 = 0, 0, time.perf_counter()
+    while time.perf_counter() - t0 < SECONDS / 2:
+        sums = []
+        for i in range(200):
+            st = s1 if i % 2 == 0 else s2
+            bt, dXs, dF, dG, obj, ref = sets[(i % 2) % len(sets)]
+            with torch.cuda.stream(st):
+                bt.eval(dXs[(i // 2) % 4], dF, dG, obj=obj, B=B)
+                sums.append((torch.stack([dF.view(torch.int64).sum(), dG.view(torch.int64).sum(), obj.view(torch.int64).sum()]), ref[(i // 2) % 4]))
+        torch.cuda.synchronize()
+        bad += sum(int((g != w).any().item()) for g, w in sums)
+        n += 200
+    print(f"{label}: {n} evaluations in {time.perf_counter() - t0:.1f} s, {bad} differ from the first evaluation of their X buffer", flush=True)
+    bad_total += bad
+    for t in sets:
+        t[0].close()
+
 # The SNOPT callback (host x -> host F, G), single trajectory: F and G are poisoned before every call, so an entry a call did
 # not write (a finalizing wave lost, a completion word seen before the data) shows as well as a wrong one.
 import numpy as np
