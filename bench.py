@@ -30,8 +30,9 @@ for N > 1, directly as `python -m torch.distributed.run --nnodes=1 --nproc-per-n
 Every timed region is preceded by at least --warmup steps AND at least 0.25 s of back-to-back launching (a fresh box
 ramps its clocks over the first milliseconds; `warmup_steps_run` says how many steps that took), and followed by a
 calibration of the box in the same process: the vendor's fill kernel and the bare store loop of the launch's own
-shape (`roofline.box_fill_GBs`, `box_stream_shape_GBs`, `frac_of_box_fill`, `frac_of_box_stream_shape`), so that a
-slow box can be told from a slow kernel.
+shape (`roofline.box_fill_GBs`, `box_stream_shape_GBs`, `frac_of_box_fill`, `vs_bare_store_loop`), so that a
+slow box can be told from a slow kernel.  Both are reference points measured beside the evaluation, not ceilings: the
+evaluation overlaps its loads with its stores and has read 1.00-1.03 x the bare store loop of its own shape.
 """
 import argparse
 import json
@@ -199,7 +200,7 @@ def device_record(tol_amd, torch, cfg, workload, mission, aircraft, ts, B, dtype
            "placement": getattr(bt, "placement", None)}
     if B > 8:       # callback-sized launches take the one-workgroup-per-trajectory kernel: no stream shape to calibrate
         shape_gbs, shape_us = store_shape_rate(bt, torch, dXs, dF, dG, B, ts, 104)
-        rec.update(box_stream_shape_GBs=shape_gbs, box_stream_shape_us=shape_us, frac_of_box_stream_shape=gbs / shape_gbs)
+        rec.update(box_stream_shape_GBs=shape_gbs, box_stream_shape_us=shape_us, vs_bare_store_loop=gbs / shape_gbs)
     bt.close()
     del dXs, dF, dG
     torch.cuda.empty_cache()
@@ -541,11 +542,279 @@ def stated_config_records(tol_amd, job, x_buffers, keep=None):
                                  "same allocation)" if r["buffers_reused"] else "its own allocation"),
                      "frac_of_box_fill": alg_total / (r["kern_ms"] * 1e-3) / 1e9 / (r["box_fill_GBs"] * world),
                      "box_stream_shape_GBs": r.get("box_stream_shape_GBs"), "box_stream_shape_us": r.get("box_stream_shape_us"),
-                     "frac_of_box_stream_shape": (alg_total / (r["kern_ms"] * 1e-3) / 1e9 / (r["box_stream_shape_GBs"] * world)
+                     "vs_bare_store_loop": (alg_total / (r["kern_ms"] * 1e-3) / 1e9 / (r["box_stream_shape_GBs"] * world)
                                                   if r.get("box_stream_shape_GBs") else None),
                      "note": "eval_us = slowest rank's time per launch (HIP events on its launch stream); gather_us = one synchronous "
                              "all-gather of the objectives alone; fractions are of n_gpus x 8 TB/s"})
+        if cfg == 3:
+            # the worst point of the scaling curve explains itself: a share of this 25 MB launch is latency-bound
+            recs[-1]["expected_scaling"] = {
+                "per_gpu_batch": {str(n): -(-G // n) for n in (1, 2, 4, 8)},
+                "launch_us_measured_on_one_gpu": {"1024": 38.1, "512": 23.8, "256": 16.0, "128": 12.4},
+                "collective_us_per_step": "11-13 (one-rank RCCL rehearsal, profiles/r04_bench_line_1rank_rccl.json: 39.2 -> 52.1 us per step)",
+                "expect": "a single device-resident trajectory already costs 10.8-12.4 us (one wave's life), so 1024 trajectories over 8 GPUs "
+                          "(128 each) read ~1.7-3.4 x one GPU, not 8 x: strong scaling of a 25 MB launch is latency-bound; the weak-scaling "
+                          "headline (8192 per GPU, 280 us launches) is the curve to read for bandwidth"}
     return recs
+
+
+def device_identity(torch, ordinal):
+    """What tells one GPU from another: ordinal, name, PCI bus id (torch's device properties where they carry it, else the HIP
+    runtime's hipDeviceGetPCIBusId), uuid where known."""
+    props = torch.cuda.get_device_properties(ordinal)
+    bus = None
+    if all(hasattr(props, a) for a in ("pci_domain_id", "pci_bus_id", "pci_device_id")):
+        bus = "%04x:%02x:%02x.0" % (props.pci_domain_id, props.pci_bus_id, props.pci_device_id)
+    else:
+        try:
+            import ctypes as C
+            import tol_amd
+            tol_amd.lib()
+            buf = C.create_string_buffer(64)
+            if tol_amd.capi._hip_runtime.hipDeviceGetPCIBusId(buf, 64, int(ordinal)) == 0:
+                bus = buf.value.decode()
+        except Exception:      # noqa: BLE001
+            bus = None
+    return {"device": int(ordinal), "name": props.name, "pci_bus_id": bus, "uuid": str(getattr(props, "uuid", "")) or None,
+            "cus": getattr(props, "multi_processor_count", None)}
+
+
+def rank_evidence(torch, dist, job, args, banner):
+    """What the N > 1 line needs to prove which devices ran: every rank's identity card, gathered on rank 0."""
+    from tol_amd.distributed import shard_bounds
+    card = dict(device_identity(torch, torch.cuda.current_device()), rank=job.rank, local_rank=job.local, pid=os.getpid(),
+                host=os.uname().nodename)
+    if args.global_batch > 0:
+        card["shard"] = list(shard_bounds(args.global_batch, job.rank, job.world))
+    else:
+        card["shard"] = [job.rank * args.batch, (job.rank + 1) * args.batch]
+    cards = [card]
+    if job.collective:
+        cards = [None] * job.world
+        dist.all_gather_object(cards, card)
+    seen = dist.get_world_size() if job.collective else 1
+    rccl = {"torch_nccl_version": None, "banner": banner or None}
+    try:
+        rccl["torch_nccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception:      # noqa: BLE001
+        pass
+    problems = []
+    if seen != args.gpus:
+        problems.append(f"the process group has {seen} ranks, --gpus says {args.gpus}")
+    if job.collective and job.backend == "nccl":
+        ids = [(c["host"], c["pci_bus_id"] or ("ordinal %d" % c["device"])) for c in cards]
+        if len(set(ids)) != len(ids):
+            problems.append(f"the ranks do not sit on pairwise distinct devices: {ids}")
+    return cards, seen, rccl, problems
+
+
+def capture_stdout_begin():
+    """RCCL prints its version banner on fd 1 when the first communicator comes up: catch it in a file (fd 1 is pointed at stderr
+    otherwise, main())."""
+    import tempfile
+    tmp = tempfile.TemporaryFile()
+    os.dup2(tmp.fileno(), 1)
+    return tmp
+
+
+def capture_stdout_end(tmp):
+    sys.stdout.flush()
+    os.dup2(2, 1)
+    tmp.seek(0)
+    text = tmp.read().decode(errors="replace")
+    tmp.close()
+    if text:
+        sys.stderr.write(text)
+    keep = [ln.strip() for ln in text.splitlines() if "RCCL" in ln or "NCCL" in ln or "HIP version" in ln or "ROCm version" in ln]
+    return " | ".join(keep)[:600]
+
+
+# ------------------------------------------------------------------------------------ the native C++ host path
+
+class _Raw:
+    """A device pointer as something torch can view (no ownership)."""
+
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (ptr, False), "version": 2}
+
+
+def native_workload(tol_amd, torch, devices, mission, aircraft, ts, dtype, total, steps, warmup, x_buffers, issue, scaling, what):
+    """One workload through the native several-GPUs-one-process host path (tol_amd/csrc/multi.cpp: one launch stream, one gather
+    stream and one issuing thread per device, grouped ncclAllGather of the objectives over four rotating buffers), the step loop
+    itself issued from native code (tolfg_multi_time_steps).  Inputs as bench.py's torch.distributed path makes them: initial
+    guesses generated on the device + 5 % noise, x_buffers input sets in rotation.  torch is used for that noise only."""
+    nd = len(devices)
+    m = tol_amd.Multi(mission, aircraft, ts=ts, dtype=dtype, devices=devices)
+    m.set_issue(issue)
+    t0 = time.perf_counter()
+    m.set_trajectories(make_trajectories(tol_amd, total, 0, mission, len(aircraft)))
+    setup_s = time.perf_counter() - t0
+    m.x0()
+    m.sync()
+    typestr = "<f8" if dtype == "f64" else "<f4"
+    sets = [[] for _ in range(max(x_buffers, 1))]
+    keep, shards = [], []
+    for i, d in enumerate(devices):
+        lo, hi = m.shard(i)
+        shards.append([lo, hi])
+        (dX, ldx), _, _ = m.buffers(i)
+        rows = max(hi - lo, 1)
+        with torch.cuda.device(d):
+            base = torch.as_tensor(_Raw(dX, (rows, ldx), typestr), device=torch.device("cuda", d))
+            assert base.data_ptr() == dX, "torch did not view the library's X in place"
+            gen = torch.Generator(device=base.device).manual_seed(5000000 + lo)
+            noise = torch.rand(base.shape, dtype=base.dtype, device=base.device, generator=gen) * 2 - 1
+            dt = base[:, 0].clone()
+            base += 0.05 * noise * (1 + base.abs())
+            base[:, 0] = dt.abs() + 0.01
+            sets[0].append(dX)
+            for j in range(1, len(sets)):
+                x = torch.roll(base, shifts=10 * j, dims=0).contiguous()
+                x[:, 0] = base[:, 0]
+                keep.append(x)
+                sets[j].append(x.data_ptr())
+            torch.cuda.synchronize(d)
+    # warm-up: at least `warmup` steps and MIN_WARM_S of launching
+    probe = m.time_steps(5, warm=2, x_sets=sets)
+    warm = max(int(warmup), int(math.ceil(MIN_WARM_S / max(probe["wall_us_per_step"] * 1e-6, 1e-7))))
+    t = m.time_steps(steps, warm=min(warm, 100000), x_sets=sets)
+    plain = m.time_steps(steps, warm=5, x_sets=sets, gather=False)       # the launches alone, for the cost of the gather in the step
+    obj = m.gather_wait(m.step(dX=sets[0]))
+    assert np.isfinite(obj).all() and obj.shape == (total,), "non-finite objective"
+    m.sync()
+    wall = t["wall_us_per_step"] * 1e-6
+    per_dev = t["launch_us_per_device"]
+    # algorithmic bytes of the widest shard through a host-side batch object of the same description (no GPU work)
+    bt = tol_amd.Batch(mission, aircraft, ts=ts, dtype=dtype, device=devices[0])
+    bt.set_trajectories(make_trajectories(tol_amd, shards[0][1] - shards[0][0], 0, mission, len(aircraft)))
+    alg0 = bt.algorithmic_bytes(shards[0][1] - shards[0][0])
+    bt.close()
+    rec = {"workload": what, "scaling": scaling, "n_gpus": nd, "batch": total, "batch_per_gpu": shards[0][1] - shards[0][0], "ts": ts, "dtype": dtype,
+           "steps": steps, "warmup_steps_run": warm + 2 + 5, "x_buffers": len(sets), "issue": t["issue"],
+           "ms_per_step": 1e3 * wall, "node_evals_per_s": total * ts / wall,
+           "eval_us": t["launch_us_per_step"], "eval_us_per_device": per_dev, "gather_us": t["gather_us"],
+           "issue_us_per_step": t["issue_us_per_step"],
+           "ms_per_step_without_gather": 1e-3 * plain["wall_us_per_step"], "eval_us_without_gather": plain["launch_us_per_step"],
+           "algorithmic_bytes_widest_shard": alg0,
+           "frac_of_hbm_peak": (alg0 / (t["launch_us_per_step"] * 1e-6) / 1e9 / HBM_PEAK_GBS) if t["launch_us_per_step"] > 0 else None,
+           "shards": shards, "setup_s": setup_s,
+           "note": "step loop issued from native code (tolfg_multi_time_steps): one launch per device + the asynchronous all-gather of the "
+                   "objectives on the devices' gather streams; eval_us = the slowest device's (event after its last launch - event before its "
+                   "first) / steps; gather_us = one synchronous gather alone; frac_of_hbm_peak = the widest shard's bytes over eval_us"}
+    del keep
+    m.close()
+    torch.cuda.empty_cache()
+    return rec
+
+
+def native_multi_main(args):
+    """`bench.py --native-multi N`: ONE process, tolfg_multi over devices 0..N-1 -- the path BASELINE's north star words ("host code
+    stays C++ ... RCCL over xGMI only for the final objective gather").  Prints one JSON record (merged into the bench line as
+    `native_multi` by the process that started this one)."""
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+    import torch
+    import tol_amd
+    n = args.native_multi
+    ndev = torch.cuda.device_count()
+    out = {"host_path": "native C++: tolfg_multi (tol_amd/csrc/multi.cpp), one process, one issuing thread + launch stream + gather stream per device",
+           "n_gpus": n, "devices_visible": ndev}
+    try:
+        if ndev < n:
+            raise RuntimeError(f"{n} devices asked for, {ndev} visible")
+        devices = list(range(n))
+        cards = [device_identity(torch, d) for d in devices]
+        ids = [c["pci_bus_id"] or ("ordinal %d" % c["device"]) for c in cards]
+        if len(set(ids)) != len(ids):
+            raise RuntimeError(f"the devices are not pairwise distinct: {ids}")
+        out["devices"] = cards
+        tmp = capture_stdout_begin()
+        try:
+            aircraft = AIRCRAFT5 if args.mission == "mixed" else (args.aircraft,)
+            total = args.global_batch if args.global_batch > 0 else args.batch * n
+            head = native_workload(tol_amd, torch, devices, args.mission, aircraft, args.ts, args.dtype, total, args.steps, args.warmup,
+                                   args.x_buffers, args.native_issue, "strong" if args.global_batch > 0 else "weak",
+                                   f"the headline: {args.mission} batch, ts={args.ts}, {args.dtype}, {total} trajectories over {n} device(s)")
+        finally:
+            banner = capture_stdout_end(tmp)
+        out.update(head)
+        out["value"] = head["node_evals_per_s"]
+        out["unit"] = "node-evals/s"
+        L = tol_amd.lib()
+        out["rccl"] = {"library": L.tolfg_multi_rccl_library().decode(), "version_code": L.tolfg_multi_rccl_version(), "banner": banner or None}
+        if not args.no_configs:
+            recs = []
+            for cfg, what, mission, air, G, dtype, steps in (
+                    (3, "configs[3] batch=1024 problemS10 ts=200, randomized wind/IC", "S10", ("tempest",), 1024, "f64", 200),
+                    (4, "configs[4] mixed G7+S10 batch=8192, five air-frames, ts=200", "mixed", AIRCRAFT5, 8192, "f64", 100),
+                    (4, "configs[4] mixed G7+S10 batch=8192, five air-frames, ts=200", "mixed", AIRCRAFT5, 8192, "f32", 100)):
+                r = native_workload(tol_amd, torch, devices, mission, air, 200, dtype, G, steps, 10, args.x_buffers, args.native_issue, "strong",
+                                    what + f", global batch sharded over {n} device(s)")
+                r["config"] = cfg
+                recs.append(r)
+            out["configs"] = recs
+    except Exception as exc:      # noqa: BLE001
+        import traceback
+        traceback.print_exc()
+        out["error"] = f"{type(exc).__name__}: {exc}"
+    data = (json.dumps(out) + "\n").encode()
+    while data:
+        data = data[os.write(result_fd, data):]
+    return 0 if "error" not in out else 1
+
+
+def run_native_child(n, args, issue="grouped", timeout=600):
+    """Start `bench.py --native-multi n` as a CHILD process (never an exec: this process has initialised the GPU) and return its
+    record, or a record that says why there is none."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--native-multi", str(n), "--native-issue", issue, "--steps", str(args.steps),
+           "--warmup", str(args.warmup), "--batch", str(args.batch), "--ts", str(args.ts), "--mission", args.mission,
+           "--aircraft", args.aircraft, "--dtype", args.dtype, "--x-buffers", str(args.x_buffers), "--min-warm-seconds", str(MIN_WARM_S)]
+    if args.global_batch > 0:
+        cmd += ["--global-batch", str(args.global_batch)]
+    if args.no_configs or issue != "grouped":
+        cmd.append("--no-configs")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK",
+                                                           "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID", "OMP_NUM_THREADS")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    t0 = time.perf_counter()
+    try:
+        res = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env, timeout=timeout)
+    except subprocess.TimeoutExpired:
+        return {"error": f"the native leg did not finish within {timeout} s", "n_gpus": n, "issue": issue}
+    rec = None
+    for ln in res.stdout.splitlines():
+        if ln.startswith("{") and ln.rstrip().endswith("}"):
+            try:
+                rec = json.loads(ln)
+            except ValueError:
+                rec = None
+    if rec is None:
+        rec = {"error": f"the native leg ended with code {res.returncode} and no record", "n_gpus": n, "issue": issue}
+    rec["child_wall_s"] = time.perf_counter() - t0
+    rec["child_exit_code"] = res.returncode
+    return rec
+
+
+def wait_for_pids(pids, seconds):
+    """Rank 0 waits (bounded) for the other ranks' processes to be gone, so that the native leg finds the GPUs idle."""
+    end = time.perf_counter() + seconds
+    left = [p for p in pids if p != os.getpid()]
+    while left and time.perf_counter() < end:
+        alive = []
+        for p in left:
+            try:
+                os.kill(p, 0)
+                alive.append(p)
+            except ProcessLookupError:
+                pass
+            except PermissionError:
+                alive.append(p)
+        left = alive
+        if left:
+            time.sleep(0.05)
+    return left
 
 
 def spawn_ranks(n):
@@ -611,9 +880,17 @@ def main():
     ap.add_argument("--single-rank-collectives", action="store_true",
                     help="rehearsal on a box with one GPU: a process group of ONE rank on --backend, and every collective of the "
                          "N > 1 path is issued (barrier, all-reduce of the timings, the asynchronous all-gather of the objectives)")
+    ap.add_argument("--native-multi", type=int, default=0,
+                    help="ONE process over devices 0..N-1 through the native C++ host path (tolfg_multi_*); prints that leg's record. "
+                         "A normal run starts this as a child after its own measurements and merges the record as `native_multi`")
+    ap.add_argument("--native-issue", default="grouped", choices=["grouped", "threads"],
+                    help="how the native leg issues the all-gather: one ncclGroupStart/End bracket | one call per device thread")
+    ap.add_argument("--no-native-multi", action="store_true", help="skip the native C++ leg")
     args = ap.parse_args()
 
     MIN_WARM_S, CALIBRATE = max(args.min_warm_seconds, 0.0), not args.no_calibration
+    if args.native_multi > 0:
+        sys.exit(native_multi_main(args))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # started as a plain command: nothing has touched a GPU yet, so the ranks are started from here as a CHILD
         # (never an exec) and this process only relays rank 0's line and the child's exit code
@@ -634,13 +911,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        args.gpus = world
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s) (WORLD_SIZE): refusing to report a line "
+                         f"under the wrong n_gpus\n")
+        sys.exit(2)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     ndev = torch.cuda.device_count()
     if args.backend == "gloo":
         local = local % max(ndev, 1)               # rehearsal: ranks may share a GPU
     torch.cuda.set_device(local)
     coll = world > 1 or args.single_rank_collectives
+    banner = ""
     if coll:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if world == 1:       # started as a plain command: the rendezvous of a world of one
@@ -654,6 +934,7 @@ def main():
             # eager communicator creation on this rank's GPU (RCCL over xGMI) and a first collective outside any
             # timing (RCCL builds its rings lazily).  A failure here is fatal: a scaling point measured over a
             # host-staged fallback would not be "RCCL over xGMI"; gloo is only ever chosen with --backend gloo.
+            banner_file = capture_stdout_begin()
             try:
                 # RCCL's kernels on a high-priority stream: a collective queued behind a launch that has every CU booked gets
                 # onto the chip when the first wave slots free up, not when the launch's backlog of tiles is through
@@ -671,7 +952,9 @@ def main():
                 dist.all_reduce(probe)
                 torch.cuda.synchronize()
                 assert int(probe.item()) == world
+                banner = capture_stdout_end(banner_file)
             except Exception as exc:      # noqa: BLE001
+                os.dup2(2, 1)
                 sys.stderr.write(f"bench.py rank {rank}: RCCL is not usable here: {type(exc).__name__}: {exc}\n"
                                  f"  (no fallback is taken; rerun with --backend gloo only to rehearse the step loop)\n")
                 sys.stderr.flush()
@@ -679,6 +962,15 @@ def main():
         else:
             dist.init_process_group("gloo")
     job = Job(torch, dist, world, rank, local, args.backend, collective=coll)
+    # which devices run this line: every rank's identity card on rank 0; a rank on a device another rank already has, or a
+    # process group of another size than --gpus, ends the run (a scaling point must not be reported over the wrong hardware)
+    cards, world_seen, rccl_info, problems = rank_evidence(torch, dist, job, args, banner)
+    if problems:
+        if rank == 0:
+            sys.stderr.write("bench.py: " + "; ".join(problems) + "\n")
+        if coll:
+            dist.destroy_process_group()
+        sys.exit(4)
 
     aircraft = AIRCRAFT5 if args.mission == "mixed" else (args.aircraft,)
     keep = {}        # the headline's batch and buffers: re-used by a stated config of the same workload (one GPU: configs[4] fp64)
@@ -736,11 +1028,12 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "box_fill_GBs": r["box_fill_GBs"], "frac_of_box_fill": achieved / r["box_fill_GBs"],
                          "box_stream_shape_GBs": r.get("box_stream_shape_GBs"), "box_stream_shape_us": r.get("box_stream_shape_us"),
-                         "frac_of_box_stream_shape": achieved / r["box_stream_shape_GBs"] if r.get("box_stream_shape_GBs") else None,
-                         "calibration": "measured in this process on this box right after the timed region: box_fill = the vendor's fill "
-                                        "kernel (torch fill_) over 800 MB; box_stream_shape = this launch's own grid, tile order, "
-                                        "resident-wave cap and store flavour with nothing in it but the Jacobian-slab stores "
-                                        "(tolfg_batch_set_store_shape), GB/s over the bytes it stores; frac_of_* = achieved / that",
+                         "vs_bare_store_loop": achieved / r["box_stream_shape_GBs"] if r.get("box_stream_shape_GBs") else None,
+                         "calibration": "reference points, not ceilings, measured in this process on this box right after the timed region: "
+                                        "box_fill = the vendor's fill kernel (torch fill_) over 800 MB; box_stream_shape = this launch's own "
+                                        "grid, tile order, resident-wave cap and store flavour with nothing in it but the Jacobian-slab stores "
+                                        "(tolfg_batch_set_store_shape), GB/s over the bytes it stores; frac_of_box_fill / vs_bare_store_loop = "
+                                        "achieved / that (the latter may exceed 1)",
                          "kernel": "tolfg::fg_kernel (the whole evaluation: the last tile wave of a trajectory finalizes it)",
                          "kernel_ms": r["kern_ms"],
                          "timing": "kernel_ms = (HIP event after the last launch - HIP event before the first) / steps, on the launch "
@@ -752,8 +1045,11 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "bytes_per_node": alg_bytes / max(B * args.ts, 1)},
         }
+        line["world_seen"] = world_seen
+        line["ranks"] = cards
         if coll:
             line["gather_us"] = r["gather_us"]
+            line["rccl"] = rccl_info
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
         if configs is not None:
@@ -772,14 +1068,31 @@ def main():
                 line["two_batches_two_streams"] = two_streams_record(tol_amd, torch, side, 4096, local)
                 if x_cached is not None:
                     line["headline_same_x_every_step"] = x_cached
+    if coll:
+        job.barrier()
+        dist.destroy_process_group()
+
+    if rank == 0:
+        # The native C++ host path (tolfg_multi: one process over all the devices), measured in a CHILD process after this one's
+        # work is done and -- under a launcher -- after the other ranks have gone (they exit right after the barrier above).
+        if not args.no_native_multi:
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
+            left = wait_for_pids([c["pid"] for c in cards], 30.0) if world > 1 else []
+            n_native = world if args.backend == "nccl" else min(world, max(ndev, 1))      # a gloo rehearsal shares GPUs: the native leg takes the devices there are
+            nm = run_native_child(n_native, args, "grouped")
+            if left:
+                nm["ranks_still_alive_at_start"] = left
+            if n_native != world:
+                nm["note_devices"] = f"{world} ranks shared {ndev} device(s) (gloo rehearsal): the native leg ran over {n_native}"
+            line["native_multi"] = nm
+            if n_native > 1 and "error" not in nm:
+                # the other way of issuing the collective (one call per device thread), headline only, in a process of its own
+                line["native_multi_threads"] = run_native_child(n_native, args, "threads", timeout=300)
         sys.stdout.flush()
         data = (json.dumps(line) + "\n").encode()
         while data:
             data = data[os.write(result_fd, data):]
-
-    if coll:
-        job.barrier()
-        dist.destroy_process_group()
 
 
 def same_x_record(torch, held, B, ts, steps):
@@ -814,7 +1127,7 @@ def compact_side_run(tol_amd, torch, args, B, device, steps=50):
             "kernel_ms": kms, "algorithmic_bytes_per_launch": alg, "achieved_GBs": gbs,
             "frac_of_hbm_peak": gbs / HBM_PEAK_GBS, "bytes_per_node": alg / (B * args.ts),
             "frac_of_box_fill": gbs / box_fill(torch, dF.device), "box_stream_shape_GBs": shape_gbs, "box_stream_shape_us": shape_us,
-            "frac_of_box_stream_shape": gbs / shape_gbs}
+            "vs_bare_store_loop": gbs / shape_gbs}
 
 
 if __name__ == "__main__":

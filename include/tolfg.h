@@ -166,8 +166,9 @@ void DEFINEGusrfg_(int *Status, int *n, double x[],
 /* Arrays used in place.
  * By default every DEFINEGusrfg_ call copies x into, and F and G out of, pinned staging buffers of the library
  * (17 + 190 KB at ts = 200): safe for any caller, whatever it does with its arrays between calls.
- * The kernel can instead read x and write F and G where they lie in the caller's memory (no copies: 18.5 vs ~30 us
- * per call at ts = 200).  That needs the arrays pinned and mapped into the GPU's address space
+ * The kernel can instead read x and write F and G where they lie in the caller's memory: no copies, 16.8 us per call at
+ * ts = 200 against 23.8 us staged (BENCH_r04, driver's box) -- i.e. 1.19e7 against 8.4e6 collocation-node evaluations
+ * per second: the >= 1e7 callback rate is met ONLY under the in-place contract.  That needs the arrays pinned and mapped into the GPU's address space
  * (hipHostRegister), and a pinning is tied to the ADDRESS, not to the allocation: an array that is freed and
  * re-allocated -- even at the same address -- is no longer the memory the GPU writes.  So in-place use is a contract
  * the caller enters explicitly, one of two ways:
@@ -318,9 +319,9 @@ int  tolfg_batch_kernel_time(tolfg_batch *b, double *avg_ms, double *min_ms);
 /* Measurement aid (calibration of a box).  While enabled, tolfg_batch_eval launches -- instead of the evaluation -- a
  * bare store loop in the evaluation's own launch shape: the same grid (one wave per tile), tile order over the XCDs,
  * resident-wave cap and store flavour (non-temporal or plain), every wave writing the 16-byte vectors of its tile's
- * Jacobian slab region with a constant; no loads, no arithmetic.  Its rate is what the write path of THIS box gives
- * THIS stream shape; bench.py measures it in the same process as the evaluation (roofline.box_stream_shape_GBs).
- * F and G hold garbage while it is on. */
+ * Jacobian slab region with a constant; no loads, no arithmetic.  Its rate is a reference point for THIS stream shape on THIS
+ * box, measured by bench.py in the same process as the evaluation (roofline.box_stream_shape_GBs, vs_bare_store_loop) -- not a
+ * ceiling: the evaluation has read 1.00-1.03 x of it.  F and G hold garbage while it is on. */
 int  tolfg_batch_set_store_shape(tolfg_batch *b, int enable);
 
 /* algorithmic bytes one evaluation of trajectories [0,B) moves: elemsize * sum of (n + neF + neG)
@@ -354,14 +355,52 @@ int  tolfg_multi_set_wind_tables(tolfg_multi *m, const double *wind_enu);
 int  tolfg_multi_x0(tolfg_multi *m);
 /* one evaluation of every shard: one launch per device, asynchronous */
 int  tolfg_multi_eval(tolfg_multi *m, int needF, int needG);
+/* the same, every device reading its shard's x rows from dX[device_index] (a device pointer ON that device, row stride as
+ * tolfg_multi_buffers reports) instead of from the library's own X: warm starts, inputs in rotation */
+int  tolfg_multi_eval_from(tolfg_multi *m, const void *const *dX, int n_devices, int needF, int needG);
 /* ncclAllGather of the objectives over the devices, then waits for all of them; host_obj (optional): `total` values of
  * the batch dtype in global trajectory order.  Reports a lost objective partial of any device (tolfg_batch_status). */
 int  tolfg_multi_gather_objectives(tolfg_multi *m, void *host_obj);
+/* The gather without the wait.  Every device has a launch stream and a (high-priority) gather stream, and
+ * TOLFG_MULTI_SLOTS = 4 objective buffers in rotation.  tolfg_multi_gather_begin enqueues the all-gather of the objectives of
+ * the evaluation issued last on the gather streams, behind an event on the launch streams, and returns a ticket at once;
+ * the next tolfg_multi_eval writes the next buffer and runs BESIDE the gather (a launch only ever waits for the gather four
+ * back, and puts nothing into its stream when that one is done, as it normally is).  tolfg_multi_gather_wait(ticket)
+ * waits for that gather on every device, reports a lost objective partial, and (host_obj != NULL) delivers the `total`
+ * objectives in global trajectory order.  A ticket is valid until four further gathers have begun (TOLFG_ERR_ARG after).
+ * tolfg_multi_step = eval (dX as in tolfg_multi_eval_from, or NULL for the library's X; F always) + gather_begin. */
+enum { TOLFG_MULTI_SLOTS = 4 };
+int  tolfg_multi_gather_begin(tolfg_multi *m, unsigned long *ticket);
+int  tolfg_multi_gather_wait(tolfg_multi *m, unsigned long ticket, void *host_obj);
+int  tolfg_multi_step(tolfg_multi *m, const void *const *dX, int n_devices, int needG, unsigned long *ticket);
+/* How the collective is issued.  GROUPED (default): one ncclGroupStart / ncclGroupEnd bracket around the devices' calls,
+ * from the caller's thread.  THREADS: every device's issuing thread calls for its own communicator, no group (NCCL's
+ * one-thread-per-device form); a tolfg_multi_step then needs no rendezvous of the host threads.  Same results. */
+enum { TOLFG_MULTI_ISSUE_GROUPED = 0, TOLFG_MULTI_ISSUE_THREADS = 1 };
+int  tolfg_multi_set_issue(tolfg_multi *m, int mode);
+/* Candidates of the per-device placement search for the G buffers (tolfg_batch_alloc_outputs) that the NEXT
+ * tolfg_multi_set_trajectories runs, the devices searching side by side on their own threads: default 12 (each device holds
+ * its candidates within half of its free memory, ~0.05 s per candidate); 0 or 1 = one allocation, no search. */
+int  tolfg_multi_set_placement(tolfg_multi *m, int tries);
+/* Measurement aid (bench.py --native-multi): `warm` untimed steps, then `steps` steps issued from native code between two
+ * full synchronisations.  A step = one launch per device (+ the asynchronous gather when gather != 0).  dX: n_x sets of
+ * per-device X pointers, dX[j * n_devices + i], used in rotation (n_x = 0: the library's own X).  launch_us_per_device
+ * (NULL or [n_devices]): (HIP event after the device's last launch - before its first) / steps. */
+typedef struct tolfg_multi_timing {
+    double wall_us_per_step;     /* host clock, first issue to everything complete, / steps                           */
+    double launch_us_per_step;   /* the slowest device's launch_us_per_device                                         */
+    double issue_us_per_step;    /* host time spent issuing, / steps                                                  */
+    double gather_us;            /* one synchronous gather (begin + wait), nothing else in flight; 0 without gather   */
+    int    devices, steps, issue;
+} tolfg_multi_timing;
+int  tolfg_multi_time_steps(tolfg_multi *m, int n_x, const void *const *dX, int needF, int needG, int gather, int warm, int steps,
+                            tolfg_multi_timing *out, double *launch_us_per_device);
 /* Monte-Carlo mean of the objectives: one ncclAllReduce(sum) of the per-device partial sums */
 int  tolfg_multi_mean_objective(tolfg_multi *m, double *mean);
 int  tolfg_multi_sync(tolfg_multi *m);
-/* which librccl was loaded ("" before the first tolfg_multi_create) */
+/* which librccl was loaded ("" before the first tolfg_multi_create) and its ncclGetVersion code (0 = unknown) */
 const char *tolfg_multi_rccl_library(void);
+int  tolfg_multi_rccl_version(void);
 
 /* The sharding rule and the re-ordering of an all-gather's equally sized blocks into global trajectory order, for
  * callers that run their own collectives (one process per GPU: tol_amd/distributed.py uses the same rule). */
@@ -375,6 +414,21 @@ const char *tolfg_default_root(void);
  * values found (may exceed maxn; only maxn are stored) or TOLFG_ERR_PARAM if unreadable. */
 int tolfg_read_params(const char *path, double *out, int maxn);
 const char *tolfg_version(void);
+/* 1 in tol_amd/lib/libtolfg_measure.so (the same sources compiled with -DTOLFG_MEASURE: it also reads the measurement
+ * variables tabled in tol_amd/csrc/knobs.h), 0 in the shipped library */
+int tolfg_measurement_build(void);
+
+/* ------------------------------------------------------------------ Environment
+ * The shipped library reads exactly three environment variables, once per process, and none of them changes which kernel
+ * an evaluation runs (tol_amd/csrc/knobs.h holds the table, measurement build included):
+ *   TOLFG_RCCL_LIBRARY=path       the collective library tolfg_multi_create loads, instead of its own search (the copy
+ *                                 the process already holds, else the one beside the HIP runtime in use); final: that
+ *                                 library or an error
+ *   TOLFG_TRACE=1                 DEFINEGusrfg_ prints one line per call on stderr: stage+launch / wait / copy-out times
+ *   TOLFG_MULTI_SHARED_DEVICES=1  test seam: tolfg_multi_create accepts a device ordinal more than once.  Honoured only
+ *                                 together with TOLFG_RCCL_LIBRARY (RCCL itself refuses such a list), and announced on
+ *                                 stderr.  Never set in production.
+ */
 
 #ifdef __cplusplus
 }

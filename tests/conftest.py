@@ -29,3 +29,11 @@ def tolfg():
         build.build()
     tol_amd.lib()
     return tol_amd
+
+
+@pytest.fixture(scope="session")
+def measure(tolfg):
+    """The measurement build of the library (tol_amd/lib/libtolfg_measure.so): the same sources with the measurement
+    variables of tol_amd/csrc/knobs.h compiled in.  A/B tests that force a launch form build their objects with
+    `library=measure`; the shipped library ignores those variables."""
+    return tolfg.measure_lib()

@@ -60,3 +60,16 @@ def assert_close_f32(F, G, Fo, Go, iG, N, mask=None, what="", scale=1.0):
             worst[(tag, cname)] = assert_close(np.asarray(arr)[m], np.asarray(ref)[m], tol=scale * FP32_TOL[cname], mask=sub,
                                                what=f"{what} {tag} class {cname}")
     return worst
+
+
+def assert_close_f32_batch(F, G, Fo, Go, iG, N, mask=None, what=""):
+    """assert_close_f32 for a whole batch at once: F, G, Fo, Go are [trajectories][entries]; the row classes are column sets."""
+    worst = {}
+    for arr, ref, rows, msk, tag in ((F, Fo, np.arange(Fo.shape[1]), None, "F"), (G, Go, iG, mask, "G")):
+        for cname, m in row_class_masks(rows, N, jacobian=tag == "G").items():
+            if not m.any():
+                continue
+            sub = None if msk is None else np.broadcast_to(msk[m], ref[:, m].shape)
+            worst[(tag, cname)] = assert_close(np.asarray(arr)[:, m], np.asarray(ref)[:, m], tol=FP32_TOL[cname], mask=sub,
+                                               what=f"{what} {tag} class {cname}")
+    return worst

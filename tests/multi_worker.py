@@ -18,8 +18,91 @@ def trajectories(tolfg, mission, total):
                              href=8.0 + 0.25 * t, xi=3.0 * t - 20.0, yi=-1.5 * t, zi=-35.0 - t) for t in range(total)]
 
 
+class _Raw:
+    """A device pointer as something torch can view (no ownership)."""
+
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (ptr, False), "version": 2}
+
+
+def pipeline(out, mission, dtype, total, parts, N, issue):
+    """The asynchronous gather (tolfg_multi_step / gather_begin / gather_wait) against the synchronous one: `nsteps` steps on
+    different inputs, the host waiting for gather j-1 only after it has issued step j, then the same inputs one by one through
+    eval_from + gather_objectives.  Also: a ticket that has expired, the native step loop, the state after it."""
+    import json
+    import torch
+    import tol_amd as tolfg
+    air = ["tempest", "skywalker"]
+    trajs = trajectories(tolfg, mission, total)
+    m = tolfg.Multi(mission, air, ts=N, dtype=dtype, devices=[0] * parts)
+    m.set_issue(issue)
+    m.set_placement(2)
+    m.set_trajectories(trajs)
+    m.x0()
+    m.sync()
+    res = {"library": np.array(m.rccl_library()), "shards": np.array([m.shard(i) for i in range(parts)])}
+    nsteps = 2 * tolfg.capi.MULTI_SLOTS + 3
+    tdt = torch.float64 if dtype == "f64" else torch.float32
+    sets, keep = [], []
+    for j in range(nsteps):
+        ptrs = []
+        for i in range(parts):
+            lo, hi = m.shard(i)
+            (dX, ldx), _, _ = m.buffers(i)
+            base = torch.as_tensor(_Raw(dX, (max(hi - lo, 1), ldx), "<f8" if dtype == "f64" else "<f4"), device="cuda:0")
+            assert base.data_ptr() == dX
+            x = base.clone()
+            x[:, 1:] *= 1.0 + 2e-3 * j           # set 0 = the initial guesses themselves
+            keep.append(x)
+            ptrs.append(x.data_ptr())
+        sets.append(ptrs)
+    torch.cuda.synchronize()
+    tickets, got = [], []
+    for j in range(nsteps):
+        tickets.append(m.step(dX=sets[j]))
+        if j >= 1:
+            got.append(m.gather_wait(tickets[j - 1]))      # step j is issued: its evaluation runs beside this wait
+    got.append(m.gather_wait(tickets[-1]))
+    res["obj_async"] = np.stack(got)
+    res["tickets"] = np.array(tickets)
+    # a run of steps nobody waits for: the first ticket expires, the last is good
+    run = [m.step(dX=sets[j % nsteps]) for j in range(tolfg.capi.MULTI_SLOTS + 2)]
+    try:
+        m.gather_wait(run[0])
+        res["expired"] = np.array("no error")
+    except tolfg.TolfgError as e:
+        res["expired"] = np.array(f"{e.code} {e}")
+    res["obj_run_last"] = m.gather_wait(run[-1])
+    res["run_last_set"] = np.array((tolfg.capi.MULTI_SLOTS + 1) % nsteps)
+    # the synchronous form on the same inputs
+    sync = []
+    for j in range(nsteps):
+        m.eval_from(sets[j])
+        sync.append(m.gather_objectives())
+    res["obj_sync"] = np.stack(sync)
+    res["mean_last"] = np.array(m.mean_objective())
+    # the native step loop, with and without the gather; then the object still works
+    tim = [m.time_steps(12, warm=3, x_sets=sets[:5]), m.time_steps(12, warm=3, x_sets=sets[:5], gather=False), m.time_steps(5, warm=0)]
+    res["timing"] = np.array(json.dumps(tim))
+    m.eval_from(sets[1])
+    res["obj_after_loop"] = m.gather_objectives()
+    m.close()
+    # the single batch on set 0 (= the initial guesses)
+    bt = tolfg.Batch(mission, air, ts=N, dtype=dtype)
+    bt.set_trajectories(trajs)
+    dX, dF, dG = bt.alloc(total)
+    bt.x0_device(dX)
+    bt.eval(dX, dF, dG)
+    torch.cuda.synchronize()
+    res["obj_single"] = dF[:, 0].cpu().numpy()
+    bt.close()
+    np.savez(out, **res)
+
+
 def main():
     out, mission, dtype, total, parts, N, wind = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6]), sys.argv[7]
+    if wind.startswith("pipeline:"):
+        return pipeline(out, mission, dtype, total, parts, N, wind.split(":")[1])
     import torch
     import tol_amd as tolfg
     from helpers import random_wind_table

@@ -36,6 +36,19 @@ def test_plain_command_with_two_ranks_prints_one_line(tmp_path):
     assert line["config"]["global_batch"] == 2 * line["config"]["batch_per_gpu"]
     assert line["value"] > 0 and 0 < line["roofline"]["frac"] < 1 and line["gather_us"] > 0
     assert sorted((r["config"], r["dtype"], r["n_gpus"]) for r in line["configs"]) == [(3, "f64", 2), (4, "f32", 2), (4, "f64", 2)]
+    # what ran where: one identity card per rank, the size of the process group as the ranks saw it
+    B = line["config"]["batch_per_gpu"]
+    assert line["world_seen"] == 2 and [c["rank"] for c in line["ranks"]] == [0, 1]
+    assert [c["shard"] for c in line["ranks"]] == [[0, B], [B, 2 * B]]
+    assert all(c["name"] and c["pid"] > 0 and "device" in c and "pci_bus_id" in c for c in line["ranks"])
+    assert len({c["pid"] for c in line["ranks"]}) == 2
+    cfg3 = [r for r in line["configs"] if r["config"] == 3][0]
+    assert cfg3["expected_scaling"]["per_gpu_batch"]["8"] == 128
+    # the native C++ leg, started by rank 0 as a child once the other rank had gone: one device here (two gloo ranks shared it)
+    nm = line["native_multi"]
+    assert "error" not in nm, nm
+    assert nm["n_gpus"] == 1 and "note_devices" in nm and nm["value"] > 0 and nm["gather_us"] > 0 and "rccl" in nm["rccl"]["library"]
+    assert "ranks_still_alive_at_start" not in nm
 
 
 @pytest.mark.gpu
@@ -54,3 +67,27 @@ def test_the_rccl_calls_of_the_multi_rank_path_run_with_one_rank():
     assert line["n_gpus"] == 1 and "rccl" in line["backend"] and "ONE rank" in line["backend"]
     assert line["value"] > 0 and 0 < line["roofline"]["frac"] < 1 and line["gather_us"] > 0
     assert any(r.get("gather_us", 0) > 0 for r in line["configs"] if r["mode"] == "device-resident" and r["config"] in (3, 4))
+    # what RCCL saw
+    assert line["world_seen"] == 1 and len(line["ranks"]) == 1
+    card = line["ranks"][0]
+    assert card["rank"] == 0 and card["device"] == 0 and card["shard"] == [0, 2048] and card["name"] and card["pci_bus_id"]
+    assert line["rccl"]["torch_nccl_version"]
+    # the native C++ host path in the same line: the same step -- launch + gather -- through tolfg_multi over
+    # device 0 and real RCCL, the step loop issued from native code
+    nm = line["native_multi"]
+    assert "error" not in nm, nm
+    assert nm["n_gpus"] == 1 and nm["issue"] == "grouped" and nm["batch_per_gpu"] == 2048 and nm["steps"] == 5
+    assert nm["value"] > 0 and nm["eval_us"] > 0 and nm["gather_us"] > 0 and nm["ms_per_step"] >= 1e-3 * nm["eval_us"] * 0.98
+    assert "rccl" in nm["rccl"]["library"] and nm["rccl"]["version_code"] > 0
+    assert nm["devices"][0]["pci_bus_id"] == card["pci_bus_id"]
+    assert 0.7 < nm["ms_per_step"] / line["ms_per_step"] < 1.3          # the same work per step on the same device
+    assert sorted((r["config"], r["dtype"]) for r in nm["configs"]) == [(3, "f64"), (4, "f32"), (4, "f64")]
+
+
+def test_a_process_group_of_another_size_than_gpus_is_refused():
+    """`--gpus 1` under a launcher that started two ranks: no line under the wrong n_gpus (exit code 2, before any GPU work)."""
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2"], capture_output=True, text=True,
+                         timeout=300, env=env, cwd=ROOT)
+    assert res.returncode == 2 and "WORLD_SIZE" in res.stderr
+    assert not [ln for ln in res.stdout.splitlines() if ln.startswith("{")]

@@ -206,3 +206,31 @@ def test_wind_model_codes_the_reference_leaves_empty_are_accepted_and_others_ref
         with pytest.raises(tolfg.TolfgError) as e:
             tolfg.Problem("S10", "tempest", ts=20, windmodel=wm)
         assert e.value.code == tolfg.capi.ERR_ARG
+
+
+def test_the_shipped_library_holds_three_environment_variables_and_the_measurement_build_the_table(tolfg):
+    """`strings libtolfg.so | grep -c TOLFG_` <= 4.  tol_amd/csrc/knobs.h tables every variable; the shipped
+    library carries the three it documents in include/tolfg.h ("Environment"), the measurement build all of them."""
+    import os
+    import re
+    import subprocess
+    here = os.path.dirname(os.path.abspath(tolfg.capi.__file__))
+
+    def names(path):
+        out = subprocess.run(["strings", path], capture_output=True, text=True, check=True).stdout
+        return sorted({m for ln in out.splitlines() for m in re.findall(r"TOLFG_[A-Z0-9_]+", ln)}), sum("TOLFG_" in ln for ln in out.splitlines())
+    shipped, lines = names(os.path.join(here, "lib", "libtolfg.so"))
+    assert shipped == ["TOLFG_MULTI_SHARED_DEVICES", "TOLFG_RCCL_LIBRARY", "TOLFG_TRACE"] and lines <= 4
+    with open(os.path.join(here, "csrc", "knobs.h")) as fh:
+        table = set(re.findall(r"^//\s+(TOLFG_[A-Z0-9_]+)", fh.read(), flags=re.M))
+    measured, _ = names(os.path.join(here, "lib", "libtolfg_measure.so"))
+    assert set(measured) == table and len(table) > 20
+    with open(os.path.join(os.path.dirname(here), "include", "tolfg.h")) as fh:
+        header = fh.read()
+    assert all(v in header for v in shipped)
+    assert tolfg.measure_lib().tolfg_measurement_build() == 1
+    # no other file of the product calls getenv
+    for f in os.listdir(os.path.join(here, "csrc")):
+        if f.endswith((".cpp", ".hip", ".h")) and f != "knobs.cpp":
+            with open(os.path.join(here, "csrc", f)) as fh:
+                assert "getenv" not in fh.read(), f

@@ -77,12 +77,16 @@ def test_node_parallel_x0_equals_the_serial_walk_bit_for_bit(tolfg, mission, dty
     dXs = torch.full_like(dXp, float("nan"))
     dXp.fill_(float("nan"))
     bt.x0_device(dXp)
+    # the serial reference form: a batch object of the measurement build created under TOLFG_X0_SERIAL (tol_amd/csrc/knobs.h)
     os.environ["TOLFG_X0_SERIAL"] = "1"
     try:
-        bt.x0_device(dXs)
+        bs = tolfg.Batch(mission, AIRCRAFT, ts=N, dtype=dtype, library=tolfg.measure_lib())
     finally:
         del os.environ["TOLFG_X0_SERIAL"]
+    bs.set_trajectories(trajs)
+    bs.x0_device(dXs)
     torch.cuda.synchronize()
+    bs.close()
     a, b = dXp[:, :bt.n].cpu().numpy(), dXs[:, :bt.n].cpu().numpy()
     assert np.isfinite(b).all()
     bad = np.argwhere(a != b)

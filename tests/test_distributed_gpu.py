@@ -54,7 +54,7 @@ def test_bench_line_carries_the_stated_configs_on_more_than_one_rank(tmp_path):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "2", "--batch", "512",
-           "--backend", "gloo"]
+           "--backend", "gloo", "--no-native-multi"]      # (the native leg: tests/test_bench_spawn.py)
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
     line = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])

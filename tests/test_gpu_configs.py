@@ -5,7 +5,7 @@ import os
 import numpy as np
 import pytest
 
-from helpers import assert_close, assert_close_f32
+from helpers import assert_close_f32_batch, assert_close, assert_close_f32
 
 pytestmark = pytest.mark.gpu
 
@@ -162,26 +162,20 @@ def test_config5_mixed_missions_all_airframes_8192(tolfg, oracle, dtype):
         # a row's tail beyond its own mission's sizes is never written
         assert np.isnan(Fa[off::2, neF:]).all() and np.isnan(Ga[off::2, neG:]).all()
         check_exact_structure(G, 3 * N + 4 if m == "S10" else N + 6, N, Xs[off::2])
+        # ALL 4096 trajectories of the mission against the oracle, evaluated as a batch on the host's cores (fp64 since round 4; the
+        # fp32 leg since round 5 -- until then every 64th trajectory was compared and the rest only met the structure checks above).
+        # fp32: the oracle is evaluated at the float32-rounded inputs the kernel saw, and compared per row class.
+        idx = list(range(off, B, 2))
+        probs = [_oracle_for(oracle, m, trajs[t], zis[t], N) for t in idx]
+        Fo, Go, _ = oracle.eval_batch(probs, Xs[idx], nthreads=min(16, len(os.sched_getaffinity(0))))
+        mask = probs[0].undefined_mask()
         if dtype == "f64":
-            # ALL 4096 trajectories of the mission against the oracle, evaluated as a batch on the host's cores (round 4; until then
-            # every 32nd one was compared and the rest only met the structure checks above)
-            idx = list(range(off, B, 2))
-            probs = [_oracle_for(oracle, m, trajs[t], zis[t], N) for t in idx]
-            Fo, Go, _ = oracle.eval_batch(probs, Xs[idx], nthreads=min(16, len(os.sched_getaffinity(0))))
-            mask = probs[0].undefined_mask()
             assert_close(Fa[idx, :neF], Fo, what=f"cfg5 {m} F (all {len(idx)} trajectories)")
             assert_close(Ga[idx, :neG], Go, mask=np.broadcast_to(mask, Go.shape), what=f"cfg5 {m} G (all {len(idx)} trajectories)")
-            continue
-        for t in range(off, B, 64):          # fp32: every 32nd trajectory of each mission against the oracle, per row class
-            o = _oracle_for(oracle, m, trajs[t], zis[t], N)
-            Fo, Go = o.eval(Xs[t])
-            if dtype == "f64":
-                assert_close(Fa[t, :neF], Fo, what=f"cfg5 {m} F[{t}]")
-                assert_close(Ga[t, :neG], Go, mask=o.undefined_mask(), what=f"cfg5 {m} G[{t}]")
-            else:
-                w = assert_close_f32(Fa[t, :neF], Ga[t, :neG], Fo, Go, pats[m], N, mask=o.undefined_mask(), what=f"cfg5 {m} f32 [{t}]")
-                for k, v in w.items():
-                    worst[(m,) + k] = max(worst.get((m,) + k, 0.0), v)
+        else:
+            w = assert_close_f32_batch(Fa[idx, :neF], Ga[idx, :neG], Fo, Go, pats[m], N, mask=mask, what=f"cfg5 {m} f32 (all {len(idx)} trajectories)")
+            for k, v in w.items():
+                worst[(m,) + k] = max(worst.get((m,) + k, 0.0), v)
     if worst:
         print("fp32 worst scaled error per class:", {k: f"{v:.2e}" for k, v in sorted(worst.items())})
 
@@ -330,7 +324,7 @@ def test_slab_stream_at_every_alignment(tolfg, oracle, mission, N, dtype):
 
 @pytest.mark.parametrize("fused", ["1", "0"])
 @pytest.mark.parametrize("mission,tail", [("S10", "7:16"), ("mixed", "20:32"), ("G7", "33:8")])
-def test_finer_tiled_tail_gives_the_same_results(tolfg, oracle, monkeypatch, mission, tail, fused):
+def test_finer_tiled_tail_gives_the_same_results(tolfg, measure, oracle, monkeypatch, mission, tail, fused):
     """TOLFG_TAIL=count:nt (a measurement knob, off by default: profiles/r02_tail_tiles.md) cuts the last `count`
     trajectories of a launch into finer tiles.  Defects and the Jacobian must be bitwise what the plain tiling
     gives; the objective is summed over different tile partials, so 1e-13."""
@@ -339,7 +333,7 @@ def test_finer_tiled_tail_gives_the_same_results(tolfg, oracle, monkeypatch, mis
     def run(env):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
-        bt = tolfg.Batch(mission, AIRCRAFT, ts=N)
+        bt = tolfg.Batch(mission, AIRCRAFT, ts=N, library=measure)
         ms = [("S10", "G7")[t % 2] if mission == "mixed" else mission for t in range(B)]
         bt.set_trajectories([tolfg.Trajectory(aircraft=t % 5, mission=ms[t], radius_goal=100.0 if ms[t] == "S10" else 0.0,
                                               Vref=1.0 + 0.1 * t) for t in range(B)])

@@ -20,7 +20,7 @@ def torch_isnan(t):
 
 
 @pytest.mark.parametrize("seed", range(6))
-def test_single_launch_equals_two_launch_on_random_shapes(tolfg, monkeypatch, seed):
+def test_single_launch_equals_two_launch_on_random_shapes(tolfg, measure, monkeypatch, seed):
     import torch
     rng = np.random.default_rng(900 + seed)
     for case in range(6):
@@ -36,7 +36,7 @@ def test_single_launch_equals_two_launch_on_random_shapes(tolfg, monkeypatch, se
         for fused in ("1", "0"):
             monkeypatch.setenv("TOLFG_FUSED", fused)
             monkeypatch.setenv("TOLFG_NO_SINGLE_LAUNCH", "1")        # small batches through the tile-per-workgroup kernels too
-            bt = tolfg.Batch(mission, AIRCRAFT, ts=N, dtype=dtype, pattern=pattern)
+            bt = tolfg.Batch(mission, AIRCRAFT, ts=N, dtype=dtype, pattern=pattern, library=measure)
             bt.set_trajectories(trajs)
             dX, dF, dG = bt.alloc(B)
             bt.x0_device(dX)
@@ -58,7 +58,7 @@ def test_single_launch_equals_two_launch_on_random_shapes(tolfg, monkeypatch, se
 
 
 @pytest.mark.parametrize("seed", range(4))
-def test_rows_through_lds_in_two_passes_equal_one_pass(tolfg, monkeypatch, seed):
+def test_rows_through_lds_in_two_passes_equal_one_pass(tolfg, measure, monkeypatch, seed):
     """FgArgs::sub_nodes = 32 (a tile's Jacobian rows go through LDS 32 nodes at a time, TOLFG_SUB_NODES) against the
     whole-tile form: bitwise the same F and G, for slab regions on and off 16-byte boundaries (odd ts; G7 rows in fp32), both
     patterns, tiles of 33..64 nodes, short last tiles, and a G buffer that itself sits 0..15 elements off a 64-byte boundary."""
@@ -78,7 +78,7 @@ def test_rows_through_lds_in_two_passes_equal_one_pass(tolfg, monkeypatch, seed)
         for sub in ("0", "32"):
             monkeypatch.setenv("TOLFG_SUB_NODES", sub)
             monkeypatch.setenv("TOLFG_NO_SINGLE_LAUNCH", "1")
-            bt = tolfg.Batch(mission, AIRCRAFT, ts=N, dtype=dtype, pattern=pattern)
+            bt = tolfg.Batch(mission, AIRCRAFT, ts=N, dtype=dtype, pattern=pattern, library=measure)
             bt.set_trajectories(trajs)
             dX, dF, dGfull = bt.alloc(B)
             ld = dGfull.shape[1]
@@ -128,3 +128,45 @@ def test_first_evaluation_on_a_non_blocking_stream_finalizes_every_trajectory(to
         bt.status()
         bt.close()
     src.close()
+
+
+@pytest.mark.parametrize("wind", ["table", "grid"])
+def test_set_up_followed_at_once_by_an_evaluation_on_a_non_blocking_stream(tolfg, wind):
+    """VERDICT r4 item 5, the audit of the race above: everything an evaluation reads besides X -- the trajectory table, a wind
+    table, a wind grid -- is uploaded either on the launch stream (tolfg_batch_eval's first call) or by a call that drains the
+    device before it returns (set_wind_grid, set_wind_table), never by null-stream work a non-blocking launch could overtake.
+    Fresh objects, described and evaluated at once on a non-blocking stream, no synchronisation in between; every one must give
+    the first one's numbers."""
+    import torch
+    from helpers import random_wind_table
+    from test_wind_grid import make_grid
+    N, B = 64, 6
+    stream = torch.cuda.Stream()
+    g = make_grid(5)
+    tables = np.stack([random_wind_table(N, 40 + t) for t in range(B)])
+    ref = None
+    for trial in range(80):
+        # the trajectories differ from object to object, so that a stale table of the object before would show
+        k = trial % 2
+        trajs = [tolfg.Trajectory(aircraft=0, radius_goal=100.0, xi=37.0 + 2.0 * t + k, yi=-41.0 - t, zi=-45.0, Vref=1.0 + t + k) for t in range(B)]
+        bt = tolfg.Batch("S10", ["tempest"], ts=N, windmodel=tolfg.capi.WIND_TABLE if wind == "table" else tolfg.capi.WIND_SHEAR)
+        bt.set_trajectories(trajs)
+        dW = None
+        if wind == "grid":
+            bt.set_wind_grid(g["v"] * (1.0 + k), g["origin"], g["spacing"], g["datum"])
+        with torch.cuda.stream(stream):
+            X, F, G = bt.alloc(B)
+            if wind == "table":
+                dW = torch.from_numpy(tables * (1.0 + k)).to("cuda", non_blocking=True)
+            bt.x0_device(X)
+            bt.eval(X, F, G, wind=dW)
+        stream.synchronize()
+        got = (F[:, :bt.neF].clone(), G[:, :bt.neG].clone())
+        assert torch.isfinite(got[0]).all()
+        if trial < 2:
+            ref = (ref or []) + [got]
+        else:
+            assert torch.equal(got[0], ref[k][0]) and torch.equal(got[1], ref[k][1]), trial
+        bt.status()
+        bt.close()
+    assert not torch.equal(ref[0][0], ref[1][0])

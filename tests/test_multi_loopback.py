@@ -55,7 +55,7 @@ def test_an_explicit_collective_library_that_cannot_be_loaded_is_an_error_not_a_
 
 
 def run_worker(tmp_path, mission, dtype, total, parts, N, wind):
-    out = str(tmp_path / f"multi_{mission}_{dtype}_{total}_{parts}.npz")
+    out = str(tmp_path / f"multi_{mission}_{dtype}_{total}_{parts}_{wind.replace(':', '_')}.npz")
     env = dict(os.environ, TOLFG_MULTI_SHARED_DEVICES="1", TOLFG_RCCL_LIBRARY=loopback_library(), HSA_ENABLE_IPC_MODE_LEGACY="0")
     res = subprocess.run([sys.executable, os.path.join(HERE, "multi_worker.py"), out, mission, dtype, str(total), str(parts), str(N), wind],
                          capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
@@ -109,3 +109,33 @@ def test_several_parts_on_one_device(tolfg, oracle, tmp_path, mission, dtype, to
             Fo, Go = o.eval(r["Xs"][t][:o.n])
             assert_close(F1[t][:len(Fo)], Fo, what=f"F of trajectory {t}")
             assert_close(G1[t][:len(Go)], Go, mask=o.undefined_mask(), what=f"G of trajectory {t}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("issue", ["grouped", "threads"])
+@pytest.mark.parametrize("mission,dtype,total,parts,N", [("mixed", "f64", 23, 4, 200), ("S10", "f32", 9, 4, 52)])
+def test_asynchronous_gather_equals_the_synchronous_one(tolfg, tmp_path, mission, dtype, total, parts, N, issue):
+    """tolfg_multi_step / gather_begin / gather_wait on 4 loop-back parts -- 11 steps on different inputs over
+    4 rotating objective buffers, the host waiting for gather j-1 with evaluation j already issued -- deliver bitwise what
+    eval_from + the synchronous gather_objectives deliver, in both ways of issuing the collective (one group call; one call
+    per device thread).  A ticket expires after 4 further gathers; the native step loop (tolfg_multi_time_steps) leaves the
+    object in working order."""
+    import json
+    r = run_worker(tmp_path, mission, dtype, total, parts, N, "pipeline:" + issue)
+    assert "loopback_nccl" in str(r["library"])
+    a, s = r["obj_async"], r["obj_sync"]
+    assert a.shape == s.shape == (11, total) and np.isfinite(a).all()
+    assert np.array_equal(a, s)
+    assert list(r["tickets"]) == list(range(11))
+    assert not np.array_equal(a[0], a[1])                                  # the inputs really differ from step to step
+    assert np.array_equal(a[0], r["obj_single"])                           # set 0 = the initial guesses: the single batch's objectives
+    assert str(r["expired"]).startswith(str(tolfg.capi.ERR_ARG)) and "ticket" in str(r["expired"])
+    assert np.array_equal(r["obj_run_last"], s[int(r["run_last_set"])])
+    assert float(r["mean_last"]) == pytest.approx(float(s[-1].astype(np.float64).mean()), rel=1e-12 if dtype == "f64" else 1e-6)
+    assert np.array_equal(r["obj_after_loop"], s[1])
+    tim = json.loads(str(r["timing"]))
+    for t, gather in zip(tim, (True, False, True)):
+        assert t["issue"] == issue and t["devices"] == parts
+        assert t["wall_us_per_step"] > 0 and t["launch_us_per_step"] > 0 and len(t["launch_us_per_device"]) == parts
+        assert (t["gather_us"] > 0) == gather
+        assert t["wall_us_per_step"] >= 0.5 * t["launch_us_per_step"]

@@ -16,8 +16,8 @@ AIRCRAFT = ["tempest", "skywalker", "tempest_eric", "tempest_wences", "tempest_w
 
 
 def _batch(tolfg, monkeypatch, mission, N, **kw):
-    monkeypatch.setenv("TOLFG_TILE_NODES", "128")
-    return tolfg.Batch(mission, AIRCRAFT, ts=N, dtype="f32", **kw)
+    monkeypatch.setenv("TOLFG_TILE_NODES", "128")      # read by the measurement build only (tol_amd/csrc/knobs.h)
+    return tolfg.Batch(mission, AIRCRAFT, ts=N, dtype="f32", library=tolfg.measure_lib(), **kw)
 
 
 def _trajs(tolfg, mission, B):
@@ -142,7 +142,7 @@ def test_packed_and_one_node_per_lane_agree(tolfg, monkeypatch):
     out = {}
     for nodes in ("64", "128"):
         monkeypatch.setenv("TOLFG_TILE_NODES", nodes)
-        bt = tolfg.Batch("mixed", AIRCRAFT, ts=N, dtype="f32")
+        bt = tolfg.Batch("mixed", AIRCRAFT, ts=N, dtype="f32", library=tolfg.measure_lib())
         _, trajs = _trajs(tolfg, "mixed", B)
         bt.set_trajectories(trajs)
         dX, dF, dG = bt.alloc(B)
@@ -158,3 +158,38 @@ def test_packed_and_one_node_per_lane_agree(tolfg, monkeypatch):
     assert (np.abs(G1 - G2) <= 4e-5 * (1 + np.abs(G1))).all()
     assert (np.abs(F1[:, 1:] - F2[:, 1:]) <= 4e-5 * (1 + np.abs(F1[:, 1:]))).all()
     assert (np.abs(F1[:, 0] - F2[:, 0]) <= 2e-6 * (1 + np.abs(F1[:, 0]))).all()
+
+
+def test_the_shipped_library_ignores_the_measurement_variables(tolfg, monkeypatch):
+    """tol_amd/csrc/knobs.h: the shipped libtolfg.so reads no variable that selects a kernel.  Under TOLFG_TILE_NODES=128 it runs
+    what it runs without it -- bitwise what the measurement build runs when told to keep 64-node tiles -- while the
+    measurement build under the same variable switches to the packed kernels (different sin/cos: different bits)."""
+    import torch
+    N, B = 200, 64
+    _, trajs = _trajs(tolfg, "mixed", B)
+
+    def run(library, nodes):
+        if nodes is None:
+            monkeypatch.delenv("TOLFG_TILE_NODES", raising=False)
+        else:
+            monkeypatch.setenv("TOLFG_TILE_NODES", nodes)
+        bt = tolfg.Batch("mixed", AIRCRAFT, ts=N, dtype="f32", library=library)
+        bt.set_trajectories(trajs)
+        dX, dF, dG = bt.alloc(B)
+        bt.x0_device(dX)
+        dX[:, 1:bt.n] *= 1.01
+        dF.zero_(); dG.zero_()
+        bt.eval(dX, dF, dG)
+        torch.cuda.synchronize()
+        out = (dF.clone(), dG.clone())
+        bt.close()
+        return out
+    if tolfg.lib().tolfg_measurement_build():
+        pytest.skip("the suite runs against the measurement build (TOLFG_LIBRARY): nothing shipped to check")
+    plain = run(tolfg.lib(), None)
+    shipped = run(tolfg.lib(), "128")
+    measured64 = run(tolfg.measure_lib(), "64")
+    measured128 = run(tolfg.measure_lib(), "128")
+    assert torch.equal(shipped[0], plain[0]) and torch.equal(shipped[1], plain[1])
+    assert torch.equal(measured64[0], plain[0]) and torch.equal(measured64[1], plain[1])
+    assert not torch.equal(measured128[1], plain[1])

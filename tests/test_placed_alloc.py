@@ -106,3 +106,40 @@ def test_dropping_a_placed_buffer_while_a_launch_still_writes_it_is_safe(tolfg):
     torch.cuda.synchronize()
     assert torch.isfinite(keepF[:, :bt.neF]).all()
     bt.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fail_at", [1, 0])
+def test_a_candidate_that_cannot_be_had_ends_the_search_and_leaves_the_batch_usable(tolfg, measure, monkeypatch, fail_at):
+    """a failure inside the placement probe must not leave the batch with the probe's (destroyed) stream as its
+    'last stream', nor throw away the candidates already timed.  Fault injection (measurement build, TOLFG_PLACE_FAIL_AT):
+    candidate 1 fails -> the search ends, candidate 0 (timed) is kept; candidate 0 fails -> an error, and Batch.alloc falls
+    back to torch's allocator.  Either way the next evaluation -- on ANOTHER stream -- runs and matches a plain buffer."""
+    import torch
+    B, N = 1600, 200                      # outputs beyond the cache: the placement search runs
+    trajs = [tolfg.Trajectory(aircraft=0, radius_goal=100.0, Vref=0.5 + 0.001 * t, xi=float(t % 13)) for t in range(B)]
+    monkeypatch.setenv("TOLFG_PLACE_FAIL_AT", str(fail_at))
+    monkeypatch.setenv("TOLFG_PLACE_EARLY", "0")                  # no early accept: the search would go on but for the failure
+    bt = tolfg.Batch("S10", ["tempest"], ts=N, library=measure)
+    bt.set_trajectories(trajs)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    X0, F0, G0 = bt.alloc(B, placed=False)
+    bt.x0_device(X0)
+    with torch.cuda.stream(s1):
+        bt.eval(X0, F0, G0)              # the stream contract now remembers s1
+    s1.synchronize()
+    if fail_at == 0:
+        with pytest.raises(tolfg.TolfgError):
+            bt.alloc_outputs(B, tries=4)
+        X, F, G = bt.alloc(B)            # the advertised fallback
+        assert bt.placement["candidates"] == 0 and "torch" in bt.placement["allocator"]
+    else:
+        G = bt.alloc_outputs(B, tries=4)
+        assert bt.placement["candidates"] == 1      # one candidate timed; the failed one is not one
+        F = torch.zeros_like(F0)
+    with torch.cuda.stream(s2):          # a different stream than the one before the probe: drains s1 (alive), not the probe's
+        bt.eval(X0, F, G)
+    s2.synchronize()
+    assert torch.equal(G[:, :bt.neG], G0[:, :bt.neG]) and torch.equal(F[:, :bt.neF], F0[:, :bt.neF])
+    bt.status()
+    bt.close()

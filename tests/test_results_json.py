@@ -6,16 +6,23 @@ import json
 import numpy as np
 import pytest
 
-REF_KEYS = {
-    "top": {"args", "problem", "FinalCost", "dt", "trajectory", "aircraft", "gains", "limits", "snopt"},
-    "args": {"east", "north", "up", "xg", "yg", "zg", "rd", "aircraft", "problem"},
-    "trajectory": {"time", "x", "y", "z", "Va", "gam", "chi", "phi", "CL", "dphi", "dCL", "T"},
-    "aircraft": {"name", "mass", "b", "S", "e", "AR", "Cd0", "CLmin", "CLmax", "phimax", "Vamin", "Vamax", "gammamax",
-                 "dphimax", "Tmin", "Tmax"},
-    "gains": {"kT", "kp", "kv", "ka", "kdt"},
-    "limits": {"dtmin", "dtmax", "xmin", "xmax", "ymin", "ymax", "zmin", "zmax"},
-    "snopt": {"ts", "numinp", "numstates", "numbounds", "opt_tol", "feas_tol"},
-}
+import os
+
+# The key names the reference's writer assigns, extracted from its text at fixture time (tools/make_ref_vectors.py --set json-keys
+# reads src/problem.cpp's writeJSON; names only are stored) -- not typed in here: a typo shared by this test and the product's
+# writer would otherwise pass.
+with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "results_json_keys.json")) as _fh:
+    _GOLDEN = json.load(_fh)
+REF_KEYS = {k: set(v) for k, v in _GOLDEN["keys"].items()}
+
+
+def test_the_golden_key_set_is_the_reference_writers():
+    assert "writeJSON" in _GOLDEN["source"]
+    assert set(REF_KEYS) == {"top", "args", "trajectory", "aircraft", "gains", "limits", "snopt"}
+    assert REF_KEYS["top"] == {"args", "problem", "FinalCost", "dt", "trajectory", "aircraft", "gains", "limits", "snopt"}
+    assert sum(len(v) for v in REF_KEYS.values()) == 65
+    # what the reference's consumers read (msl/mission.py:208-226) is there
+    assert {"time", "x", "y", "z"} <= REF_KEYS["trajectory"] and "dt" in REF_KEYS["top"]
 
 
 @pytest.mark.parametrize("mission,aircraft", [("S10", "tempest"), ("G7", "skywalker")])

@@ -5,8 +5,8 @@ include/tolfg.h).  This package is the thin Python host layer over that ABI: cty
 buffers through torch, and the one-process-per-GPU batch driver.  There is no CPU fallback: every
 evaluation needs a gfx950 device and raises TolfgError otherwise.
 """
-from .capi import TolfgError, lib, lib_path   # noqa: F401
+from .capi import TolfgError, lib, lib_path, measure_lib   # noqa: F401
 from . import capi                             # noqa: F401
 from .host import Batch, Multi, Problem, Trajectory, device_alloc  # noqa: F401
 
-__all__ = ["Batch", "Multi", "Problem", "Trajectory", "TolfgError", "capi", "lib", "lib_path"]
+__all__ = ["Batch", "Multi", "Problem", "Trajectory", "TolfgError", "capi", "device_alloc", "lib", "lib_path", "measure_lib"]

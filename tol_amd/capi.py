@@ -56,6 +56,15 @@ class BatchConfig(C.Structure):
                 ("pattern", C.c_int)]
 
 
+class MultiTiming(C.Structure):
+    _fields_ = [("wall_us_per_step", C.c_double), ("launch_us_per_step", C.c_double), ("issue_us_per_step", C.c_double),
+                ("gather_us", C.c_double), ("devices", C.c_int), ("steps", C.c_int), ("issue", C.c_int)]
+
+
+MULTI_SLOTS = 4
+ISSUE_GROUPED, ISSUE_THREADS = 0, 1
+_vpp = C.POINTER(C.c_void_p)
+
 # snFunA, include/snopt/snopt.h:60-66 of the reference
 SNFUNA = C.CFUNCTYPE(None, _ip, _ip, _dp, _ip, _ip, _dp, _ip, _ip, _dp, C.c_char_p, _ip, _ip, _ip, _dp, _ip)
 
@@ -124,6 +133,16 @@ SYMBOLS = {
     "tolfg_multi_x0": (C.c_int, [C.c_void_p]),
     "tolfg_multi_eval": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "tolfg_multi_gather_objectives": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "tolfg_multi_eval_from": (C.c_int, [C.c_void_p, _vpp, C.c_int, C.c_int, C.c_int]),
+    "tolfg_multi_gather_begin": (C.c_int, [C.c_void_p, C.POINTER(C.c_ulong)]),
+    "tolfg_multi_gather_wait": (C.c_int, [C.c_void_p, C.c_ulong, C.c_void_p]),
+    "tolfg_multi_step": (C.c_int, [C.c_void_p, _vpp, C.c_int, C.c_int, C.POINTER(C.c_ulong)]),
+    "tolfg_multi_set_issue": (C.c_int, [C.c_void_p, C.c_int]),
+    "tolfg_multi_set_placement": (C.c_int, [C.c_void_p, C.c_int]),
+    "tolfg_multi_time_steps": (C.c_int, [C.c_void_p, C.c_int, _vpp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                         C.POINTER(MultiTiming), _dp]),
+    "tolfg_multi_rccl_version": (C.c_int, []),
+    "tolfg_measurement_build": (C.c_int, []),
     "tolfg_multi_mean_objective": (C.c_int, [C.c_void_p, _dp]),
     "tolfg_multi_sync": (C.c_int, [C.c_void_p]),
     "tolfg_multi_rccl_library": (C.c_char_p, []),
@@ -132,12 +151,19 @@ SYMBOLS = {
 }
 
 _lib = None
+_measure_lib = None
 _hip_runtime = None
 
 
 def lib_path():
-    """The product library; TOLFG_LIBRARY names another build of it (same-box A/B of two builds, tools/)."""
+    """The product library; TOLFG_LIBRARY names another build of it (same-box A/B of two builds, tools/; the GPU suite
+    against the measurement build)."""
     return os.environ.get("TOLFG_LIBRARY") or os.path.join(HERE, "lib", "libtolfg.so")
+
+
+def measure_lib_path():
+    """The measurement build: the same sources with the measurement variables of csrc/knobs.h compiled in."""
+    return os.path.join(HERE, "lib", "libtolfg_measure.so")
 
 
 def hip_runtime_path():
@@ -176,29 +202,43 @@ def mapped_hip_runtimes():
     return sorted(out)
 
 
+def _load(path):
+    """Load one build of the library.  Fails loudly when it has not been built (no fallback path exists)."""
+    if not os.path.exists(path):
+        raise TolfgError(ERR_HIP, f"{path} is missing: run `python -m tol_amd.build` (hipcc, gfx950)")
+    # libtolfg.so carries no DT_NEEDED for the HIP runtime (csrc/Makefile explains why): make the
+    # process-wide copy globally visible first, then load the library against it.
+    global _hip_runtime
+    if _hip_runtime is None:
+        _hip_runtime = C.CDLL(hip_runtime_path(), mode=C.RTLD_GLOBAL)
+    L = C.CDLL(path)
+    if len(mapped_hip_runtimes()) > 1:
+        raise TolfgError(ERR_HIP, "two HIP runtimes are mapped: %s" % mapped_hip_runtimes())
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    return L
+
+
 def lib():
-    """Load libtolfg.so.  Fails loudly when it has not been built (no fallback path exists)."""
+    """The product library (tol_amd/lib/libtolfg.so, or the build TOLFG_LIBRARY names)."""
     global _lib
     if _lib is None:
-        path = lib_path()
-        if not os.path.exists(path):
-            raise TolfgError(ERR_HIP, f"{path} is missing: run `python -m tol_amd.build` (hipcc, gfx950)")
-        # libtolfg.so carries no DT_NEEDED for the HIP runtime (csrc/Makefile explains why): make the
-        # process-wide copy globally visible first, then load the library against it.
-        global _hip_runtime
-        _hip_runtime = C.CDLL(hip_runtime_path(), mode=C.RTLD_GLOBAL)
-        L = C.CDLL(path)
-        if len(mapped_hip_runtimes()) > 1:
-            raise TolfgError(ERR_HIP, "two HIP runtimes are mapped: %s" % mapped_hip_runtimes())
-        for name, (res, args) in SYMBOLS.items():
-            fn = getattr(L, name)
-            fn.restype = res
-            fn.argtypes = args
-        _lib = L
+        _lib = _load(lib_path())
     return _lib
 
 
-def check(rc):
+def measure_lib():
+    """The measurement build, for tools and A/B tests: pass it as `library=` to Problem / Batch / Multi.  Objects remember
+    the library that made them, so both builds can serve one process side by side."""
+    global _measure_lib
+    if _measure_lib is None:
+        _measure_lib = _load(measure_lib_path())
+    return _measure_lib
+
+
+def check(rc, L=None):
     if rc != OK:
-        raise TolfgError(rc, lib().tolfg_last_error().decode())
+        raise TolfgError(rc, (L or lib()).tolfg_last_error().decode())
     return rc

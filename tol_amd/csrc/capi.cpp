@@ -11,6 +11,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include "../../include/tolfg.h"
+#include "knobs.h"
 #include "problem.h"
 #include "multi.h"
 
@@ -25,6 +26,7 @@ struct tolfg_batch {
 };
 struct tolfg_multi {
     multi *m;
+    int place_tries;
 };
 
 namespace {
@@ -69,7 +71,8 @@ int guarded(Fn &&fn)
 extern "C" {
 
 const char *tolfg_last_error(void) { return g_err.c_str(); }
-const char *tolfg_version(void) { return "tolfg-mi355x 0.1 (gfx950)"; }
+const char *tolfg_version(void) { return measurement_build() ? "tolfg-mi355x 0.2 (gfx950, measurement build)" : "tolfg-mi355x 0.2 (gfx950)"; }
+int tolfg_measurement_build(void) { return measurement_build() ? 1 : 0; }
 
 const char *tolfg_default_root(void)
 {
@@ -497,7 +500,7 @@ int tolfg_multi_create(const tolfg_batch_config *cfg, const int *devices, int n_
         }
         const std::string root = cfg->root_path ? std::string(cfg->root_path) : default_root();
         *out = new tolfg_multi{new multi(cfg->mission, root, names, cfg->ts, cfg->windmodel, cfg->dtype, cfg->pattern,
-                                        std::vector<int>(devices, devices + n_devices))};
+                                        std::vector<int>(devices, devices + n_devices)), 12};
     });
 }
 
@@ -521,7 +524,7 @@ int tolfg_multi_sizes(const tolfg_multi *h, int *n, int *neF, int *neG)
 int tolfg_multi_set_trajectories(tolfg_multi *h, long total, const tolfg_traj *trajs)
 {
     if (!h) return fail(TOLFG_ERR_ARG, "null handle");
-    return guarded([&] { h->m->set_trajectories(total, trajs); });
+    return guarded([&] { h->m->set_trajectories(total, trajs, h->place_tries); });
 }
 
 int tolfg_multi_shard(const tolfg_multi *h, int i, long *lo, long *hi)
@@ -560,6 +563,71 @@ int tolfg_multi_eval(tolfg_multi *h, int needF, int needG)
 {
     if (!h) return fail(TOLFG_ERR_ARG, "null handle");
     return guarded([&] { h->m->eval(needF != 0, needG != 0); });
+}
+
+int tolfg_multi_set_placement(tolfg_multi *h, int tries)
+{
+    if (!h || tries < 0) return fail(TOLFG_ERR_ARG, "tolfg_multi_set_placement: bad argument");
+    h->place_tries = tries;
+    return TOLFG_OK;
+}
+
+int tolfg_multi_set_issue(tolfg_multi *h, int mode)
+{
+    if (!h) return fail(TOLFG_ERR_ARG, "null handle");
+    return guarded([&] { h->m->set_issue(mode); });
+}
+
+int tolfg_multi_eval_from(tolfg_multi *h, const void *const *dX, int n_devices, int needF, int needG)
+{
+    if (!h || !dX || n_devices != h->m->devices()) return fail(TOLFG_ERR_ARG, "tolfg_multi_eval_from: one X pointer per device is required");
+    return guarded([&] { h->m->eval(needF != 0, needG != 0, dX); });
+}
+
+int tolfg_multi_gather_begin(tolfg_multi *h, unsigned long *ticket)
+{
+    if (!h || !ticket) return fail(TOLFG_ERR_ARG, "null argument");
+    return guarded([&] { *ticket = h->m->gather_begin(); });
+}
+
+int tolfg_multi_gather_wait(tolfg_multi *h, unsigned long ticket, void *host_obj)
+{
+    if (!h) return fail(TOLFG_ERR_ARG, "null handle");
+    return guarded([&] { h->m->gather_wait(ticket, host_obj); });
+}
+
+int tolfg_multi_step(tolfg_multi *h, const void *const *dX, int n_devices, int needG, unsigned long *ticket)
+{
+    if (!h || !ticket || (dX && n_devices != h->m->devices())) return fail(TOLFG_ERR_ARG, "tolfg_multi_step: bad argument");
+    return guarded([&] { *ticket = h->m->step(true, needG != 0, dX); });
+}
+
+int tolfg_multi_time_steps(tolfg_multi *h, int n_x, const void *const *dX, int needF, int needG, int gather, int warm, int steps,
+                           tolfg_multi_timing *out, double *launch_us_per_device)
+{
+    if (!h || !out) return fail(TOLFG_ERR_ARG, "null argument");
+    return guarded([&] {
+        const multi::Timing t = h->m->time_steps(n_x, dX, needF != 0, needG != 0, gather != 0, warm, steps, launch_us_per_device);
+        out->wall_us_per_step = t.wall_us_per_step;
+        out->launch_us_per_step = t.launch_us_per_step;
+        out->issue_us_per_step = t.issue_us_per_step;
+        out->gather_us = t.gather_us;
+        out->devices = h->m->devices();
+        out->steps = steps;
+        out->issue = h->m->issue();
+    });
+}
+
+int tolfg_multi_rccl_version(void)
+{
+    int v = 0;
+    try {
+        const rccl_api &nc = rccl_api::get();
+        if (!nc.GetVersion || nc.GetVersion(&v) != 0) v = 0;
+    } catch (const std::exception &) {
+        v = 0;
+    }
+    return v;
 }
 
 int tolfg_multi_gather_objectives(tolfg_multi *h, void *host_obj)

@@ -125,6 +125,7 @@ struct LaunchShape {
     int aligned;           // rows of X and F on 16-byte boundaries (16-byte window loads / defect stores possible)
     double out_bytes;      // F + G bytes this launch writes
     int needG = 1;         // the Jacobian is wanted (0: F alone)
+    int cus = 256;         // compute units of the device (MI355X: 256; the batch asks the runtime)
 };
 LaunchPlan plan_launch(const LaunchShape &shape);
 

@@ -3,11 +3,13 @@
 
 #include <dlfcn.h>
 
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 
 #include "kernels.h"
+#include "knobs.h"
 
 namespace tolfg {
 
@@ -30,6 +32,11 @@ struct DeviceGuard {
 
 // rccl.h: ncclFloat32 = 7, ncclFloat64 = 8, ncclSum = 0, ncclSuccess = 0 (/opt/rocm/include/rccl/rccl.h:448-467)
 enum { kNcclFloat32 = 7, kNcclFloat64 = 8, kNcclSum = 0 };
+
+void clear_hip_errors()
+{
+    for (int i = 0; i < 4 && hipGetLastError() != hipSuccess; ++i) {}
+}
 
 void nccl_check(int rc, const char *what)
 {
@@ -83,15 +90,16 @@ const rccl_api &rccl_api::get()
     std::call_once(once, [] {
         std::vector<std::string> names;
         const std::string dir = hip_runtime_dir();
-        if (const char *e = std::getenv("TOLFG_RCCL_LIBRARY")) {
+        const std::string &named = knobs().rccl_library;          // knobs.h
+        if (!named.empty()) {
             // an explicit choice is final: that library or a failure, never a silent second pick
-            api.handle = dlopen(e, RTLD_NOW | RTLD_GLOBAL);
+            api.handle = dlopen(named.c_str(), RTLD_NOW | RTLD_GLOBAL);
             if (!api.handle) {
                 const char *why = dlerror();
-                failure = std::string("TOLFG_RCCL_LIBRARY=") + e + " cannot be loaded: " + (why ? why : "?");
+                failure = "the collective library named in the environment, " + named + ", cannot be loaded: " + (why ? why : "?");
                 return;
             }
-            api.path = e;
+            api.path = named;
         } else {
             if (!dir.empty()) { names.push_back(dir + "librccl.so.1"); names.push_back(dir + "librccl.so"); }
             names.emplace_back("librccl.so.1");
@@ -104,7 +112,7 @@ const rccl_api &rccl_api::get()
                 }
         }
         if (!api.handle) {
-            failure = "librccl was not found (tried the HIP runtime's directory '" + dir + "' and the default search path; TOLFG_RCCL_LIBRARY names one explicitly)";
+            failure = "librccl was not found (tried the HIP runtime's directory '" + dir + "' and the default search path; include/tolfg.h, \"Environment\", says how to name one)";
             return;
         }
         auto sym = [&](const char *name) {
@@ -130,12 +138,10 @@ multi::multi(const std::string &mission, const std::string &root, const std::vec
     : dev_(devices), dtype_(dtype)
 {
     if (devices.empty() || devices.size() > 64) throw std::invalid_argument("tolfg_multi: 1..64 devices");
-    // Test seam: TOLFG_MULTI_SHARED_DEVICES=1 lets an ordinal appear more than once, so that several parts -- their
-    // issuing threads, shard dealing, per-shard uploads and the padded gather -- run on a box with ONE GPU.  RCCL itself
-    // refuses duplicate devices in ncclCommInitAll, so this only works with a stand-in collective library named by
-    // TOLFG_RCCL_LIBRARY (tests/loopback_nccl).  Never set in production.
-    const char *shared = std::getenv("TOLFG_MULTI_SHARED_DEVICES");
-    if (!(shared && shared[0] == '1'))
+    // Test seam (knobs.h): with the shared-devices variable AND an explicit stand-in collective library an ordinal may appear
+    // more than once, so that several parts -- their issuing threads, shard dealing, per-shard uploads and the padded gather --
+    // run on a box with ONE GPU (tests/loopback_nccl).  RCCL itself refuses duplicate devices in ncclCommInitAll.
+    if (!knobs().multi_shared_devices)
         for (size_t i = 0; i < devices.size(); ++i)
             for (size_t j = 0; j < i; ++j)
                 if (devices[i] == devices[j]) throw std::invalid_argument("tolfg_multi: every device may appear once");
@@ -152,9 +158,22 @@ multi::multi(const std::string &mission, const std::string &root, const std::vec
         check(hipGetDeviceCount(&ndev), "hipGetDeviceCount");
         for (int d : devices)
             if (d < 0 || d >= ndev) throw std::invalid_argument("tolfg_multi: no such HIP device");
-        for (Part &p : part_) {
+        for (size_t i = 0; i < part_.size(); ++i) {
+            Part &p = part_[i];
+            p.index = (int)i;
             check(hipSetDevice(p.device), "hipSetDevice");
             check(hipStreamCreateWithFlags(&p.stream, hipStreamNonBlocking), "hipStreamCreate");
+            // the collective's kernels on a high-priority stream: a gather queued beside a launch that has every CU booked gets
+            // onto the chip when the first wave slots free up, not when the launch's backlog of tiles is through
+            int least = 0, greatest = 0;
+            if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { least = greatest = 0; clear_hip_errors(); }
+            check(hipStreamCreateWithPriority(&p.gstream, hipStreamNonBlocking, greatest), "hipStreamCreateWithPriority");
+            for (int k = 0; k < kSlots; ++k) {
+                check(hipEventCreateWithFlags(&p.ev_launch[k], hipEventDisableTiming), "hipEventCreate");
+                check(hipEventCreateWithFlags(&p.ev_gather[k], hipEventDisableTiming), "hipEventCreate");
+            }
+            check(hipEventCreate(&p.t0), "hipEventCreate");
+            check(hipEventCreate(&p.t1), "hipEventCreate");
             check(hipMalloc(&p.dSum, 2 * sizeof(double)), "hipMalloc(sum)");
         }
         const rccl_api &nc = rccl_api::get();
@@ -184,6 +203,7 @@ void multi::release()
     for (Part &p : part_) {
         (void)hipSetDevice(p.device);
         if (p.stream) (void)hipStreamSynchronize(p.stream);
+        if (p.gstream) (void)hipStreamSynchronize(p.gstream);
     }
     for (Part &p : part_)
         if (p.comm) { (void)rccl_api::get().CommDestroy(p.comm); p.comm = nullptr; }      // a comm exists only if the api loaded
@@ -193,23 +213,39 @@ void multi::release()
         if (p.dSum) (void)hipFree(p.dSum);
         p.dSum = nullptr;
         p.b.reset();
+        for (int k = 0; k < kSlots; ++k) {
+            if (p.ev_launch[k]) (void)hipEventDestroy(p.ev_launch[k]);
+            if (p.ev_gather[k]) (void)hipEventDestroy(p.ev_gather[k]);
+            p.ev_launch[k] = p.ev_gather[k] = nullptr;
+        }
+        if (p.t0) (void)hipEventDestroy(p.t0);
+        if (p.t1) (void)hipEventDestroy(p.t1);
+        p.t0 = p.t1 = nullptr;
+        if (p.gstream) (void)hipStreamDestroy(p.gstream);
         if (p.stream) (void)hipStreamDestroy(p.stream);
-        p.stream = nullptr;
+        p.stream = p.gstream = nullptr;
     }
-    for (int i = 0; i < 4 && hipGetLastError() != hipSuccess; ++i) {}
+    clear_hip_errors();
 }
 
 void multi::free_buffers()
 {
     DeviceGuard guard;
-    if (hAll_) (void)hipHostFree(hAll_);
-    hAll_ = nullptr;
+    for (int k = 0; k < kSlots; ++k) {
+        if (hAll_[k]) (void)hipHostFree(hAll_[k]);
+        hAll_[k] = nullptr;
+    }
     for (Part &p : part_) {
         (void)hipSetDevice(p.device);
-        for (void **q : {&p.dX, &p.dF, &p.dObj, &p.dAll, &p.dWind}) {
+        for (void **q : {&p.dX, &p.dF, &p.dWind}) {
             if (*q) (void)hipFree(*q);
             *q = nullptr;
         }
+        for (int k = 0; k < kSlots; ++k)
+            for (void **q : {&p.dObj[k], &p.dAll[k]}) {
+                if (*q) (void)hipFree(*q);
+                *q = nullptr;
+            }
         if (p.dG) {
             try { device_free(p.dG); } catch (const std::exception &) {}
             p.dG = nullptr;
@@ -273,7 +309,22 @@ void multi::on_every_device(const std::function<void(Part &)> &fn)
     }
 }
 
-void multi::set_trajectories(long total, const tolfg_traj *trajs)
+int multi::nccl_type() const { return dtype_ == TOLFG_F64 ? kNcclFloat64 : kNcclFloat32; }
+
+int multi::rccl_version() const
+{
+    int v = 0;
+    const rccl_api &nc = rccl_api::get();
+    return (nc.GetVersion && nc.GetVersion(&v) == 0) ? v : 0;
+}
+
+void multi::set_issue(int mode)
+{
+    if (mode != ISSUE_GROUPED && mode != ISSUE_THREADS) throw std::invalid_argument("tolfg_multi_set_issue: unknown mode");
+    issue_ = mode;
+}
+
+void multi::set_trajectories(long total, const tolfg_traj *trajs, int place_tries)
 {
     if (total < 1 || !trajs) throw std::invalid_argument("tolfg_multi_set_trajectories: at least one trajectory and a table");
     sync();
@@ -285,11 +336,14 @@ void multi::set_trajectories(long total, const tolfg_traj *trajs)
     total_ = total;
     width_ = shard_width(total, world);
     ldx_ = up(sz.n); ldf_ = up(sz.neF); ldg_ = up(sz.neG);
+    seq_ = 0;
+    last_gather_slot_ = 0;
     for (int i = 0; i < world; ++i) shard_bounds(total, i, world, &part_[i].lo, &part_[i].hi);
     {
         DeviceGuard guard;
         check(hipSetDevice(part_[0].device), "hipSetDevice");
-        check(hipHostMalloc(&hAll_, elem() * (size_t)width_ * world, hipHostMallocDefault), "hipHostMalloc(gathered)");
+        for (int k = 0; k < kSlots; ++k)
+            check(hipHostMalloc(&hAll_[k], elem() * (size_t)width_ * world, hipHostMallocDefault), "hipHostMalloc(gathered)");
     }
     on_every_device([&](Part &p) {
         check(hipSetDevice(p.device), "hipSetDevice");
@@ -298,17 +352,22 @@ void multi::set_trajectories(long total, const tolfg_traj *trajs)
         const size_t rows = (size_t)(B > 0 ? B : 1);
         check(hipMalloc(&p.dX, elem() * rows * ldx_), "hipMalloc(X)");
         check(hipMalloc(&p.dF, elem() * rows * ldf_), "hipMalloc(F)");
-        // G, the bulk of what a launch writes, comes placed for this shard's launch (problem.h: alloc_outputs)
+        // G, the bulk of what a launch writes, comes placed for this shard's launch (problem.h: alloc_outputs): up to
+        // place_tries candidates per device, held side by side within half of its free memory, ~0.05 s each, the devices
+        // searching concurrently on their own threads
         if (B > 0) {
             long ldg = 0;
-            p.dG = p.b->alloc_outputs((int)B, 12, &ldg, nullptr, nullptr);
+            p.dG = p.b->alloc_outputs((int)B, place_tries, &ldg, nullptr, nullptr);
             if (ldg != ldg_) throw std::logic_error("tolfg_multi: row stride of the placed G buffer");
         } else {
             p.dG = device_alloc(p.device, elem() * rows * ldg_);
         }
-        check(hipMalloc(&p.dObj, elem() * (size_t)width_), "hipMalloc(obj)");
-        check(hipMalloc(&p.dAll, elem() * (size_t)width_ * world), "hipMalloc(gathered)");
-        check(hipMemsetAsync(p.dObj, 0, elem() * (size_t)width_, p.stream), "hipMemsetAsync(obj)");
+        // everything below is ordered on the launch stream, ahead of the first evaluation
+        for (int k = 0; k < kSlots; ++k) {
+            check(hipMalloc(&p.dObj[k], elem() * (size_t)width_), "hipMalloc(obj)");
+            check(hipMalloc(&p.dAll[k], elem() * (size_t)width_ * world), "hipMalloc(gathered)");
+            check(hipMemsetAsync(p.dObj[k], 0, elem() * (size_t)width_, p.stream), "hipMemsetAsync(obj)");
+        }
         check(hipMemsetAsync(p.dX, 0, elem() * rows * ldx_, p.stream), "hipMemsetAsync(X)");
     });
 }
@@ -349,54 +408,143 @@ void multi::set_wind_tables(const double *wind_enu)
         if (rows == 0) return;
         check(hipSetDevice(p.device), "hipSetDevice");
         if (!p.dWind) check(hipMalloc(&p.dWind, elem() * rows * per), "hipMalloc(wind)");
+        // from pinned staging ON THE LAUNCH STREAM, which is then drained: the copy is ordered ahead of the evaluations
+        // that read it whatever the null stream does, and the staging can go
         const double *src = wind_enu + (size_t)p.lo * per;
-        if (dtype_ == TOLFG_F64) {
-            check(hipMemcpy(p.dWind, src, sizeof(double) * rows * per, hipMemcpyHostToDevice), "hipMemcpy(wind)");
-        } else {
-            std::vector<float> tmp(src, src + rows * per);
-            check(hipMemcpy(p.dWind, tmp.data(), sizeof(float) * rows * per, hipMemcpyHostToDevice), "hipMemcpy(wind)");
-        }
+        void *stage = nullptr;
+        check(hipHostMalloc(&stage, elem() * rows * per, hipHostMallocDefault), "hipHostMalloc(wind staging)");
+        if (dtype_ == TOLFG_F64) std::memcpy(stage, src, sizeof(double) * rows * per);
+        else { float *f = static_cast<float *>(stage); for (size_t i = 0; i < rows * per; ++i) f[i] = (float)src[i]; }
+        hipError_t e = hipMemcpyAsync(p.dWind, stage, elem() * rows * per, hipMemcpyHostToDevice, p.stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(p.stream);
+        (void)hipHostFree(stage);
+        check(e, "upload(wind tables)");
     });
 }
 
-void multi::eval(bool needF, bool needG)
+// ---- the pieces of a step (the part's device is current)
+
+void multi::part_eval(Part &p, int slot, bool needF, bool needG, const void *X)
+{
+    if (p.hi <= p.lo) return;
+    if (needF) {
+        // slot reuse: the gather that last read this objective buffer (kSlots gathers back) must be through.  It normally is,
+        // long ago -- then nothing is put into the launch stream (a wait marker between two launches costs the second a few us)
+        const hipError_t q = hipEventQuery(p.ev_gather[slot]);
+        if (q == hipErrorNotReady) {
+            clear_hip_errors();
+            check(hipStreamWaitEvent(p.stream, p.ev_gather[slot], 0), "hipStreamWaitEvent(slot reuse)");
+        } else if (q != hipSuccess) {
+            check(q, "hipEventQuery");
+        }
+    }
+    p.b->eval((int)(p.hi - p.lo), X ? X : p.dX, ldx_, p.dF, ldf_, p.dG, ldg_, p.dWind, needF ? 1 : 0, needG ? 1 : 0, p.stream,
+              needF ? p.dObj[slot] : nullptr);
+}
+
+void multi::part_gather_pre(Part &p, int slot)
+{
+    // the gather stream picks up where the launch stream stands now: behind the evaluation whose objectives it carries
+    check(hipEventRecord(p.ev_launch[slot], p.stream), "hipEventRecord(launch)");
+    check(hipStreamWaitEvent(p.gstream, p.ev_launch[slot], 0), "hipStreamWaitEvent(gather)");
+}
+
+void multi::part_gather_call(Part &p, int slot)
+{
+    nccl_check(rccl_api::get().AllGather(p.dObj[slot], p.dAll[slot], (size_t)width_, nccl_type(), p.comm, p.gstream), "ncclAllGather");
+}
+
+void multi::part_gather_post(Part &p, int slot)
+{
+    if (p.index == 0)      // device 0's copy of the gathered vector follows its gather on the same stream, into pinned memory
+        check(hipMemcpyAsync(hAll_[slot], p.dAll[slot], elem() * (size_t)width_ * devices(), hipMemcpyDeviceToHost, p.gstream),
+              "hipMemcpyAsync(gathered)");
+    check(hipEventRecord(p.ev_gather[slot], p.gstream), "hipEventRecord(gather)");
+}
+
+void multi::eval(bool needF, bool needG, const void *const *dX)
 {
     if (total_ < 1) throw std::invalid_argument("tolfg_multi: set_trajectories first");
+    const int slot = (int)(seq_ % kSlots);
+    on_every_device([&](Part &p) { part_eval(p, slot, needF, needG, dX ? dX[p.index] : nullptr); });
+    evaluated_since_gather_ = true;
+}
+
+unsigned long multi::gather_begin()
+{
+    if (total_ < 1) throw std::invalid_argument("tolfg_multi: set_trajectories first");
+    const int slot = (int)(seq_ % kSlots);
+    if (issue_ == ISSUE_THREADS) {
+        on_every_device([&](Part &p) { part_gather_pre(p, slot); part_gather_call(p, slot); part_gather_post(p, slot); });
+    } else {
+        // one group call from this thread: the single-process form of a collective over several devices
+        DeviceGuard guard;
+        const rccl_api &nc = rccl_api::get();
+        for (Part &p : part_) { check(hipSetDevice(p.device), "hipSetDevice"); part_gather_pre(p, slot); }
+        nccl_check(nc.GroupStart(), "ncclGroupStart");
+        for (Part &p : part_) part_gather_call(p, slot);
+        nccl_check(nc.GroupEnd(), "ncclGroupEnd");
+        for (Part &p : part_) { check(hipSetDevice(p.device), "hipSetDevice"); part_gather_post(p, slot); }
+    }
+    last_gather_slot_ = slot;
+    evaluated_since_gather_ = false;
+    return seq_++;
+}
+
+unsigned long multi::step(bool needF, bool needG, const void *const *dX)
+{
+    if (total_ < 1) throw std::invalid_argument("tolfg_multi: set_trajectories first");
+    if (!needF) throw std::invalid_argument("tolfg_multi_step: the gather carries the objectives, so F is needed");
+    if (issue_ != ISSUE_THREADS) {
+        eval(needF, needG, dX);
+        return gather_begin();
+    }
+    const int slot = (int)(seq_ % kSlots);
     on_every_device([&](Part &p) {
-        if (p.hi > p.lo)
-            p.b->eval((int)(p.hi - p.lo), p.dX, ldx_, p.dF, ldf_, p.dG, ldg_, p.dWind, needF ? 1 : 0, needG ? 1 : 0, p.stream,
-                      needF ? p.dObj : nullptr);
+        part_eval(p, slot, needF, needG, dX ? dX[p.index] : nullptr);
+        part_gather_pre(p, slot); part_gather_call(p, slot); part_gather_post(p, slot);
     });
+    last_gather_slot_ = slot;
+    evaluated_since_gather_ = false;
+    return seq_++;
+}
+
+void multi::gather_wait(unsigned long ticket, void *host_out)
+{
+    if (total_ < 1) throw std::invalid_argument("tolfg_multi: set_trajectories first");
+    if (ticket >= seq_ || seq_ - ticket > (unsigned long)kSlots)
+        throw std::invalid_argument("tolfg_multi_gather_wait: no such gather in flight (a ticket stays valid for " + std::to_string(kSlots) +
+                                    " further gathers)");
+    const int slot = (int)(ticket % kSlots);
+    {
+        DeviceGuard guard;
+        for (Part &p : part_) {
+            check(hipSetDevice(p.device), "hipSetDevice");
+            check(hipEventSynchronize(p.ev_gather[slot]), "hipEventSynchronize(gather)");
+        }
+    }
+    // the gather is behind the evaluation that fed it: that evaluation's health can be asked now
+    for (Part &p : part_)
+        if (p.b->take_lost_partial()) throw hip_failure("device " + std::to_string(p.device) + ": an evaluation lost an objective partial");
+    if (host_out) compact_gathered(hAll_[slot], elem(), total_, devices(), host_out);
 }
 
 void multi::gather_objectives(void *host_out)
 {
-    if (total_ < 1) throw std::invalid_argument("tolfg_multi: set_trajectories first");
-    const rccl_api &nc = rccl_api::get();
-    // one group call from this thread: the single-process form of a collective over several devices
-    nccl_check(nc.GroupStart(), "ncclGroupStart");
-    for (Part &p : part_)
-        nccl_check(nc.AllGather(p.dObj, p.dAll, (size_t)width_, dtype_ == TOLFG_F64 ? kNcclFloat64 : kNcclFloat32, p.comm, p.stream),
-                   "ncclAllGather");
-    nccl_check(nc.GroupEnd(), "ncclGroupEnd");
-    if (host_out) {      // device 0's copy of the gathered vector follows its gather on the same stream, into pinned memory
-        DeviceGuard guard;
-        check(hipSetDevice(part_[0].device), "hipSetDevice");
-        check(hipMemcpyAsync(hAll_, part_[0].dAll, elem() * (size_t)width_ * devices(), hipMemcpyDeviceToHost, part_[0].stream),
-              "hipMemcpyAsync(gathered)");
-    }
+    const unsigned long t = gather_begin();
+    gather_wait(t, host_out);
     sync();
-    for (Part &p : part_)
-        if (p.b->take_lost_partial()) throw hip_failure("device " + std::to_string(p.device) + ": an evaluation lost an objective partial");
-    if (host_out) compact_gathered(hAll_, elem(), total_, devices(), host_out);
 }
 
 double multi::mean_objective()
 {
     if (total_ < 1) throw std::invalid_argument("tolfg_multi: set_trajectories first");
     const rccl_api &nc = rccl_api::get();
+    // the objectives of the evaluation issued last: the slot the next gather would carry, or -- right after a gather, nothing
+    // evaluated since -- the one it carried; either way the buffer the launch stream wrote last
+    const int slot = (int)((seq_ > 0 && !evaluated_since_gather_ ? seq_ - 1 : seq_) % kSlots);
     on_every_device([&](Part &p) {
-        check(launch_sum(p.dObj, (int)(p.hi - p.lo), dtype_, static_cast<double *>(p.dSum), p.stream), "launch sum");
+        check(launch_sum(p.dObj[slot], (int)(p.hi - p.lo), dtype_, static_cast<double *>(p.dSum), p.stream), "launch sum");
     });
     nccl_check(nc.GroupStart(), "ncclGroupStart");
     for (Part &p : part_)
@@ -406,7 +554,7 @@ double multi::mean_objective()
     double s[2];
     DeviceGuard guard;
     check(hipSetDevice(part_[0].device), "hipSetDevice");
-    check(hipMemcpy(s, part_[0].dSum, sizeof s, hipMemcpyDeviceToHost), "hipMemcpy(sum)");
+    check(hipMemcpy(s, part_[0].dSum, sizeof s, hipMemcpyDeviceToHost), "hipMemcpy(sum)");      // device to host: complete on return
     return s[1] / (double)total_;
 }
 
@@ -416,7 +564,79 @@ void multi::sync()
     for (Part &p : part_) {
         check(hipSetDevice(p.device), "hipSetDevice");
         check(hipStreamSynchronize(p.stream), "hipStreamSynchronize");
+        check(hipStreamSynchronize(p.gstream), "hipStreamSynchronize(gather)");
     }
+}
+
+// ---- the native step loop (measurement aid)
+
+void multi::steps_run(int n, int n_x, const void *const *dX, bool needF, bool needG, bool gather, unsigned long first_step)
+{
+    const int world = devices();
+    if (gather && issue_ == ISSUE_THREADS) {
+        // every device's thread issues its own n steps -- launch, event, wait, its communicator's all-gather, copy, event --
+        // without meeting the other threads on the host: the collective's kernels meet on the devices
+        const unsigned long seq0 = seq_;
+        on_every_device([&](Part &p) {
+            for (int i = 0; i < n; ++i) {
+                const int slot = (int)((seq0 + (unsigned long)i) % kSlots);
+                const void *X = n_x > 0 ? dX[(size_t)((first_step + (unsigned long)i) % (unsigned long)n_x) * world + p.index] : nullptr;
+                part_eval(p, slot, needF, needG, X);
+                part_gather_pre(p, slot); part_gather_call(p, slot); part_gather_post(p, slot);
+            }
+        });
+        seq_ += (unsigned long)n;
+        if (n > 0) { last_gather_slot_ = (int)((seq_ - 1) % kSlots); evaluated_since_gather_ = false; }
+        return;
+    }
+    for (int i = 0; i < n; ++i) {
+        const void *const *X = n_x > 0 ? dX + (size_t)((first_step + (unsigned long)i) % (unsigned long)n_x) * world : nullptr;
+        if (gather) step(needF, needG, X);
+        else eval(needF, needG, X);
+    }
+}
+
+multi::Timing multi::time_steps(int n_x, const void *const *dX, bool needF, bool needG, bool gather, int warm, int steps,
+                                double *launch_us_per_device)
+{
+    if (total_ < 1) throw std::invalid_argument("tolfg_multi: set_trajectories first");
+    if (steps < 1 || warm < 0 || n_x < 0 || (n_x > 0 && !dX)) throw std::invalid_argument("tolfg_multi_time_steps: bad arguments");
+    if (gather && !needF) throw std::invalid_argument("tolfg_multi_time_steps: the gather carries the objectives, so F is needed");
+    using clk = std::chrono::steady_clock;
+    auto us = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+    Timing t;
+    steps_run(warm, n_x, dX, needF, needG, gather, 0);
+    sync();
+    on_every_device([&](Part &p) { check(hipEventRecord(p.t0, p.stream), "hipEventRecord"); });
+    const auto h0 = clk::now();
+    steps_run(steps, n_x, dX, needF, needG, gather, (unsigned long)warm);
+    const auto h1 = clk::now();
+    on_every_device([&](Part &p) { check(hipEventRecord(p.t1, p.stream), "hipEventRecord"); });
+    if (gather) gather_wait(seq_ - 1, nullptr);
+    sync();
+    const auto h2 = clk::now();
+    t.wall_us_per_step = us(h0, h2) / steps;
+    t.issue_us_per_step = us(h0, h1) / steps;
+    {
+        DeviceGuard guard;
+        for (Part &p : part_) {
+            check(hipSetDevice(p.device), "hipSetDevice");
+            float ms = 0;
+            check(hipEventElapsedTime(&ms, p.t0, p.t1), "hipEventElapsedTime");
+            const double per = p.hi > p.lo ? 1e3 * ms / steps : 0.0;
+            if (launch_us_per_device) launch_us_per_device[p.index] = per;
+            if (per > t.launch_us_per_step) t.launch_us_per_step = per;
+        }
+    }
+    if (gather) {      // the gather alone: synchronous, nothing else in flight
+        const int reps = 50;
+        for (int i = 0; i < 5; ++i) gather_wait(gather_begin(), nullptr);
+        sync();
+        const auto g0 = clk::now();
+        for (int i = 0; i < reps; ++i) gather_wait(gather_begin(), nullptr);
+        t.gather_us = us(g0, clk::now()) / reps;
+    }
+    return t;
 }
 
 }  // namespace tolfg

@@ -1,6 +1,6 @@
 // multi.h -- one process, several MI355X: a batch of independent trajectories sharded over the devices of one node,
-// one launch stream and one issuing host thread per device, and the ONE collective the path has -- the all-gather of
-// the per-trajectory objectives -- through RCCL over xGMI (BASELINE north star).
+// one launch stream, one gather stream and one issuing host thread per device, and the ONE collective the path has --
+// the all-gather of the per-trajectory objectives -- through RCCL over xGMI (BASELINE north star).
 // No reference counterpart: tol solves one trajectory per process.
 #ifndef TOLFG_MULTI_H_
 #define TOLFG_MULTI_H_
@@ -46,7 +46,12 @@ struct rccl_api {
 
 class multi {
 public:
-    // devices: HIP device ordinals, all different (TOLFG_MULTI_SHARED_DEVICES=1, a test seam, lifts that: multi.cpp).
+    // Objective buffers in rotation (dObj / dAll per device, a pinned host copy on device 0): the evaluation that follows a
+    // gather writes the next pair, so a launch never waits for the gather before it -- only for the one kSlots gathers back,
+    // which is normally long done (then nothing at all is put into the launch stream).
+    static constexpr int kSlots = 4;
+
+    // devices: HIP device ordinals, all different (knobs.h: the shared-devices test seam lifts that).
     // Communicators are created here (ncclCommInitAll).
     multi(const std::string &mission, const std::string &root, const std::vector<std::string> &aircraft_names, int ts,
           int windmodel, int dtype, int pattern, const std::vector<int> &devices);
@@ -59,8 +64,9 @@ public:
     long total() const { return total_; }
     void shard(int i, long *lo, long *hi) const { *lo = part_.at(i).lo; *hi = part_.at(i).hi; }
 
-    // describe all `total` trajectories (global order); device i keeps [lo_i, hi_i); (re)allocates X, F, G there
-    void set_trajectories(long total, const tolfg_traj *trajs);
+    // describe all `total` trajectories (global order); device i keeps [lo_i, hi_i); (re)allocates X, F, G there.
+    // place_tries: candidates of the per-device placement search for G (batch::alloc_outputs); 0 / 1 = none
+    void set_trajectories(long total, const tolfg_traj *trajs, int place_tries = 12);
     // device buffers of shard i: rows of the batch dtype in the SNOPT layout, strides in elements
     void buffers(int i, void **dX, long *ldx, void **dF, long *ldf, void **dG, long *ldg) const;
     // wind for every device: one gridded field (wind model 3), or per-trajectory tables [total][12][ts+1] of doubles in global
@@ -69,35 +75,76 @@ public:
     void set_wind_tables(const double *wind_enu);
     // initial guesses of every shard, generated on its device
     void x0();
-    // one evaluation of every shard: one launch per device, issued concurrently by the per-device host threads
-    void eval(bool needF, bool needG);
-    // all-gather of the objectives over the devices (RCCL, one group call), then wait for everything; out (optional):
-    // `total` values of the batch dtype in global trajectory order, copied from device 0
+    // one evaluation of every shard: one launch per device, issued concurrently by the per-device host threads.
+    // dX (optional): devices() device pointers, dX[i] on device i with the row stride buffers() reports -- the shard's
+    // x rows are read from there instead of from the library's own X (warm starts; rotating inputs)
+    void eval(bool needF, bool needG, const void *const *dX = nullptr);
+    // The all-gather of the objectives of the evaluation issued last, enqueued on the devices' gather streams behind an
+    // event on their launch streams: returns at once with a ticket; evaluations issued afterwards run beside it.
+    unsigned long gather_begin();
+    // waits for that gather on every device; out (optional): `total` values of the batch dtype in global trajectory
+    // order (device 0's copy).  A ticket stays valid until kSlots further gathers have begun.
+    void gather_wait(unsigned long ticket, void *host_out);
+    // eval + gather_begin in one go (one wake-up of the issuing threads per step)
+    unsigned long step(bool needF, bool needG, const void *const *dX = nullptr);
+    // gather_begin + gather_wait + wait for everything (the synchronous form)
     void gather_objectives(void *host_out);
     // Monte-Carlo mean of the objectives: all-reduce(sum) of each device's partial sum (double)
     double mean_objective();
-    // device pointer (device i) of the gathered, padded vector: devices() blocks of shard_width() values
-    const void *gathered(int i) const { return part_.at(i).dAll; }
+    // device pointer (device i) of the gathered, padded vector of the last gather: devices() blocks of shard_width() values
+    const void *gathered(int i) const { return part_.at(i).dAll[last_gather_slot_]; }
     void sync();
     std::string rccl_path() const { return rccl_api::get().path; }
+    int rccl_version() const;
+
+    // How the collective is issued.  GROUPED: one ncclGroupStart / ncclGroupEnd bracket around the devices' calls, from the
+    // caller's thread (the single-process form of the NCCL manual; the default).  THREADS: every device's own issuing thread
+    // makes its call for its communicator, no group -- the one-thread-per-device form; with it a step (launch + gather) is
+    // issued by each thread on its own, without a rendezvous of the host threads.
+    enum { ISSUE_GROUPED = 0, ISSUE_THREADS = 1 };
+    void set_issue(int mode);
+    int issue() const { return issue_; }
+
+    // Measurement aid (bench.py --native-multi): `warm` untimed steps, then `steps` steps -- launch + asynchronous gather,
+    // inputs rotating over n_x sets of caller-supplied X buffers ([n_x][devices()] device pointers; n_x = 0: the library's
+    // own X) -- between two full synchronisations, issued from native code.
+    struct Timing {
+        double wall_us_per_step = 0, launch_us_per_step = 0, issue_us_per_step = 0, gather_us = 0;
+    };
+    Timing time_steps(int n_x, const void *const *dX, bool needF, bool needG, bool gather, int warm, int steps, double *launch_us_per_device);
 
 private:
     struct Part {
-        int device = 0;
+        int device = 0, index = 0;
         long lo = 0, hi = 0;
         std::unique_ptr<batch> b;
-        hipStream_t stream = nullptr;
-        void *dX = nullptr, *dF = nullptr, *dG = nullptr, *dObj = nullptr, *dAll = nullptr, *dSum = nullptr, *dWind = nullptr;
+        hipStream_t stream = nullptr, gstream = nullptr;
+        void *dX = nullptr, *dF = nullptr, *dG = nullptr, *dSum = nullptr, *dWind = nullptr;
+        void *dObj[kSlots] = {}, *dAll[kSlots] = {};
+        hipEvent_t ev_launch[kSlots] = {}, ev_gather[kSlots] = {};
+        hipEvent_t t0 = nullptr, t1 = nullptr;
         void *comm = nullptr;
     };
     std::vector<int> dev_;
     std::vector<Part> part_;
     int dtype_;
+    int issue_ = ISSUE_GROUPED;
     long total_ = 0, width_ = 0, ldx_ = 0, ldf_ = 0, ldg_ = 0;
-    void *hAll_ = nullptr;            // pinned host copy of the gathered, padded objectives (gather_objectives with host_out)
+    unsigned long seq_ = 0;             // gathers begun so far; the next evaluation's objectives go to slot seq_ % kSlots
+    int last_gather_slot_ = 0;
+    bool evaluated_since_gather_ = false;
+    void *hAll_[kSlots] = {};           // pinned host copies of the gathered, padded objectives
     size_t elem() const { return dtype_ == TOLFG_F64 ? 8 : 4; }
+    int nccl_type() const;
     void free_buffers();
     void release();
+
+    // the pieces of a step, each on its part's device (the caller has made it current)
+    void part_eval(Part &p, int slot, bool needF, bool needG, const void *X);
+    void part_gather_pre(Part &p, int slot);
+    void part_gather_call(Part &p, int slot);
+    void part_gather_post(Part &p, int slot);
+    void steps_run(int n, int n_x, const void *const *dX, bool needF, bool needG, bool gather, unsigned long first_step);
 
     // one issuing thread per device beyond the first (the caller's thread serves device 0): launches reach the
     // devices side by side instead of one hipSetDevice + launch after the other (8 devices: ~40 us serial)

@@ -4,8 +4,6 @@
 
 namespace tolfg {
 
-namespace { constexpr long kCUs = 256; }     // MI355X
-
 void plan_tiles(int N, int dtype, int max_nt, int *tiles, int *nt)
 {
     // ceil(N/max_nt) tiles of equal size, the size rounded up to 4 nodes so that every tile's x window
@@ -78,7 +76,8 @@ LaunchPlan plan_launch(const LaunchShape &sh)
         const int t = (sh.N + 27) / 28 > 5 ? (sh.N + 27) / 28 : 5;      // tiles of <= 28 nodes, at least 5 of them
         p.max_nt = ((sh.N + t - 1) / t + 3) & ~3;
     }
-    const long waves_per_cu_launched = (tiles64 + kCUs - 1) / kCUs;
+    const long cus = sh.cus > 0 ? sh.cus : 256;
+    const long waves_per_cu_launched = (tiles64 + cus - 1) / cus;
     p.sub_nodes = (!beyond_cache && sh.dtype == 0 && !p.single && waves_per_cu_launched > 10 && waves_per_cu_launched <= 20) ? 32 : 0;
     p.nt_stores = beyond_cache ? 1 : 0;
     // fp32 compact slabs (184 bytes per node) are the one shape that wants every wave it can get beyond the cache
@@ -89,7 +88,7 @@ LaunchPlan plan_launch(const LaunchShape &sh)
     p.waves_per_cu = beyond_cache ? (sh.dtype == 0 ? 8 : (sh.pattern == PATTERN_COMPACT ? 0 : 12)) : 0;
     if (packed && sh.pattern == PATTERN_COMPACT) p.waves_per_cu = 0;
     p.xcd = 1;
-    p.stagger = (!beyond_cache && tiles64 >= 12 * 256) ? 1 : 0;
+    p.stagger = (!beyond_cache && tiles64 >= 12 * cus) ? 1 : 0;
     // one launch per evaluation, except for the compact pattern beyond the cache, where the two-launch form
     // measured 5 % faster (103.3 vs 108.0 us at B=4096: half the bytes per node, so the finalizing waves' tails weigh more)
     p.fused = (sh.pattern == PATTERN_COMPACT && beyond_cache) ? 0 : 1;

@@ -14,6 +14,8 @@
 
 #include <hip/hip_runtime_api.h>
 
+#include "knobs.h"
+
 namespace tolfg {
 
 problem *prob = nullptr;
@@ -33,6 +35,16 @@ void check(hipError_t e, const char *what)
 void clear_errors()
 {
     for (int i = 0; i < 4 && hipGetLastError() != hipSuccess; ++i) {}
+}
+
+// Set-up uploads that are not tied to a launch stream (wind grid, wind table: the caller has no evaluation in flight, as the
+// header asks).  hipMemcpy from pageable memory may return once the source is staged, before the DMA has landed, and the
+// null stream it rides is not ordered against the non-blocking streams the evaluations use: so the device is drained
+// before this returns, and whatever stream the next evaluation names finds the data in place.
+void blocking_upload(void *dst, const void *src, size_t bytes, const char *what)
+{
+    check(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice), what);
+    check(hipDeviceSynchronize(), what);
 }
 
 int kernel_wind(int windmodel)
@@ -91,7 +103,6 @@ struct DeviceBlock {
 };
 std::mutex g_blocks_mu;
 std::map<void *, DeviceBlock> g_blocks;
-constexpr size_t kPlacedChunkDefault = 2u << 20;
 
 void release_block(void *ptr, DeviceBlock &b)
 {
@@ -108,12 +119,7 @@ void release_block(void *ptr, DeviceBlock &b)
 void *device_alloc(int device, size_t bytes)
 {
     if (bytes == 0) throw std::invalid_argument("device_alloc: zero bytes");
-    // measurement: TOLFG_PLACED_CHUNK_KIB=k backs the range with chunks of k KiB (a power of two, 64 ... 1048576) instead of 2 MiB
-    size_t kPlacedChunk = kPlacedChunkDefault;
-    if (const char *e = std::getenv("TOLFG_PLACED_CHUNK_KIB")) {
-        const long k = std::atol(e);
-        if (k >= 64 && k <= (1L << 20) && (k & (k - 1)) == 0) kPlacedChunk = (size_t)k << 10;
-    }
+    const size_t kPlacedChunk = knobs().placed_chunk;       // 2 MiB (knobs.h: the measurement build can change it)
     DeviceGuardLocal guard;
     check(hipSetDevice(device), "hipSetDevice");
     DeviceBlock blk;
@@ -215,30 +221,19 @@ batch::batch(const std::string &mission, const std::string &root, const std::vec
     }
 
     args_.pattern = pattern;
-    // measurement overrides of the launch plan (plan.cpp), clamped to what launch_fg accepts: a tile size is a multiple
-    // of 4 in [4, 64] (fp32: up to 128), a resident-wave cap lies in [0, 32], a tail count is not negative
-    auto env_int = [](const char *name, int lo, int hi, int *out) {
-        const char *e = std::getenv(name);
-        if (!e) return false;
-        const int v = std::atoi(e);
-        *out = v < lo ? lo : (v > hi ? hi : v);
-        return true;
-    };
+    // overrides of the launch plan (plan.cpp): none in the shipped library; the measurement build takes them from the
+    // environment (knobs.h), clamped to what launch_fg accepts: a tile size is a multiple of 4 in [4, 64] (fp32: up to 128)
+    refresh_knobs();
+    const Knobs &kn = knobs();
     auto tile_ok = [&](int v) { return v <= 0 ? 0 : std::min(std::max(v & ~3, 4), dtype == TOLFG_F32 ? 2 * kTileNodes : kTileNodes); };
-    int v = 0;
-    if (env_int("TOLFG_WAVES_PER_CU", 0, 32, &v)) { waves_per_cu_ = v; waves_forced_ = true; }
+    if (kn.waves_per_cu >= 0) { waves_per_cu_ = kn.waves_per_cu; waves_forced_ = true; }
     args_.N = N;
     plan_tiles(N, dtype, 0, &args_.tiles, &args_.nt);      // eval() re-plans for its batch size
-    if (env_int("TOLFG_TILE_NODES", 0, 2 * kTileNodes, &v)) tile_nodes_forced_ = tile_ok(v);
-    if (env_int("TOLFG_FUSED", 0, 1, &v)) fused_forced_ = v;
-    if (env_int("TOLFG_NT_STORES", 0, 1, &v)) nt_forced_ = v;
-    if (env_int("TOLFG_XCD", 0, 1, &v)) xcd_forced_ = v;
-    if (env_int("TOLFG_STAGGER", 0, 1, &v)) stagger_forced_ = v;
-    if (env_int("TOLFG_SUB_NODES", 0, 32, &v)) sub_forced_ = v >= 32 ? 32 : 0;
-    if (const char *e = std::getenv("TOLFG_TAIL")) {        // "count:nt", count 0 = no tail
-        tail_forced_ = std::max(0, std::atoi(e));
-        if (const char *c = std::strchr(e, ':')) tail_nt_forced_ = std::min(tile_ok(std::atoi(c + 1)), kTileNodes);
-    }
+    if (kn.tile_nodes >= 0) tile_nodes_forced_ = tile_ok(kn.tile_nodes);
+    fused_forced_ = kn.fused; nt_forced_ = kn.nt_stores; xcd_forced_ = kn.xcd; stagger_forced_ = kn.stagger; sub_forced_ = kn.sub_nodes;
+    tail_forced_ = kn.tail_count;
+    if (kn.tail_nt > 0) tail_nt_forced_ = std::min(tile_ok(kn.tail_nt), kTileNodes);
+    no_single_ = kn.no_single_launch; force_single_ = kn.force_single_launch; x0_serial_ = kn.x0_serial;
     for (int m = 0; m < 2; ++m) {
         const gain &g = gains(m);
         args_.c0[m] = szm_[m].c0;
@@ -297,10 +292,10 @@ void batch::set_wind_grid(const tolfg_wind_grid &g)
     d_grid_ = nullptr;
     check(hipMalloc(&d_grid_, elem_size() * cnt), "hipMalloc(grid)");
     if (dtype_ == TOLFG_F64) {
-        check(hipMemcpy(d_grid_, g.v, sizeof(double) * cnt, hipMemcpyHostToDevice), "hipMemcpy(grid)");
+        blocking_upload(d_grid_, g.v, sizeof(double) * cnt, "upload(grid)");
     } else {
         std::vector<float> tmp(g.v, g.v + cnt);
-        check(hipMemcpy(d_grid_, tmp.data(), sizeof(float) * cnt, hipMemcpyHostToDevice), "hipMemcpy(grid)");
+        blocking_upload(d_grid_, tmp.data(), sizeof(float) * cnt, "upload(grid)");
     }
     grid_host_.assign(g.v, g.v + cnt);      // for the opt-in Woutput.txt dump (problem::dump_wind)
     GridDev &d = args_.grid;
@@ -360,22 +355,61 @@ void batch::set_trajectories(int B, const tolfg_traj *trajs)
     uploaded_ = false;     // the device copy is made by the first eval (set-up needs no GPU)
 }
 
-void batch::upload()
+void batch::upload(hipStream_t stream)
 {
+    // Everything the kernels read besides X -- the trajectory table and the initial guess's per-node table -- goes to the
+    // device ON THE STREAM OF THE CALL THAT NEEDS IT, from pinned staging, and that stream is drained before this returns:
+    // nothing here rides the null stream (which is not ordered against a non-blocking launch stream), and a later call on
+    // any other stream finds the uploads complete.  Rare (once per set_trajectories) and blocking; never inside a capture.
+    DeviceGuardLocal guard;
     check(hipSetDevice(device_), "hipSetDevice");
+    if (cus_ <= 0) {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_) == hipSuccess && cus > 0) cus_ = cus;
+        else { cus_ = 256; clear_errors(); }
+    }
     if (ntraj_ > cap_) {
         if (d_traj_) check(hipFree(d_traj_), "hipFree");
         d_traj_ = nullptr;
         check(hipMalloc(reinterpret_cast<void **>(&d_traj_), sizeof(TrajDev) * (size_t)ntraj_), "hipMalloc(traj)");
         cap_ = ntraj_;
     }
-    check(hipMemcpy(d_traj_, dev_traj_.data(), sizeof(TrajDev) * (size_t)ntraj_, hipMemcpyHostToDevice),
-          "hipMemcpy(traj)");
-    if (!h_status_) {
-        check(hipHostMalloc(reinterpret_cast<void **>(&h_status_), 64, hipHostMallocMapped), "hipHostMalloc(status)");
-        *h_status_ = 0;
-        check(hipHostGetDevicePointer(reinterpret_cast<void **>(&d_status_), h_status_, 0), "hipHostGetDevicePointer(status)");
+    const size_t traj_bytes = sizeof(TrajDev) * (size_t)ntraj_;
+    const int N = sz_.N;
+    const size_t ld = (size_t)N + 1;
+    const size_t tab_bytes = d_tgrid_ ? 0 : sizeof(double) * 2 * (size_t)X0_FIELDS * ld;
+    void *stage = nullptr;
+    check(hipHostMalloc(&stage, traj_bytes + tab_bytes, hipHostMallocDefault), "hipHostMalloc(upload staging)");
+    try {
+        std::memcpy(stage, dev_traj_.data(), traj_bytes);
+        check(hipMemcpyAsync(d_traj_, stage, traj_bytes, hipMemcpyHostToDevice, stream), "hipMemcpyAsync(traj)");
+        if (tab_bytes) {
+            // node times exactly as InitialCond forms them: t = t + dt from 0 (ref: src/problemS10.cpp:60-64); the rest of
+            // the table (what a node's row holds for every trajectory of a mission alike) is computed on the device from
+            // them, once per batch object
+            double *tg = reinterpret_cast<double *>(static_cast<char *>(stage) + traj_bytes);
+            std::memset(tg, 0, tab_bytes);
+            for (int m = 0; m < 2; ++m) {
+                const double dt = (m == 0 ? 20.0 : 10.0) / N;
+                double t = 0.0;
+                for (int k = 0; k <= N; ++k, t = t + dt) tg[(size_t)m * X0_FIELDS * ld + k] = t;
+            }
+            check(hipMalloc(reinterpret_cast<void **>(&d_tgrid_), tab_bytes), "hipMalloc(x0 table)");
+            check(hipMemcpyAsync(d_tgrid_, tg, tab_bytes, hipMemcpyHostToDevice, stream), "hipMemcpyAsync(x0 table)");
+            check(launch_x0_table(d_tgrid_, N, mission_, stream), "launch x0 table");
+        }
+        if (!h_status_) {
+            check(hipHostMalloc(reinterpret_cast<void **>(&h_status_), 64, hipHostMallocMapped), "hipHostMalloc(status)");
+            *h_status_ = 0;
+            check(hipHostGetDevicePointer(reinterpret_cast<void **>(&d_status_), h_status_, 0), "hipHostGetDevicePointer(status)");
+        }
+        check(hipStreamSynchronize(stream), "hipStreamSynchronize(upload)");
+    } catch (...) {
+        (void)hipStreamSynchronize(stream);
+        (void)hipHostFree(stage);
+        throw;
     }
+    check(hipHostFree(stage), "hipHostFree(upload staging)");
     uploaded_ = true;
 }
 
@@ -396,7 +430,7 @@ void batch::eval(int B, const void *dX, long ldx, void *dF, long ldf, void *dG, 
         throw std::invalid_argument("eval: leading dimension smaller than the row");
     if (windmodel_ == TOLFG_WIND_TABLE && !dWind && !store_shape_) throw std::invalid_argument("eval: table wind needs dWind");
     if (windmodel_ == TOLFG_WIND_GRID && !d_grid_ && !store_shape_) throw std::invalid_argument("eval: grid wind needs tolfg_*_set_wind_grid");
-    if (!uploaded_) upload();
+    if (!uploaded_) upload(stream);
     // Stream contract (include/tolfg.h): the per-launch workspace (objective partials, arrival counters) belongs to ONE
     // evaluation at a time.  Evaluations on one stream are ordered by the stream; a caller that moves to another stream
     // gets the ordering enforced here -- the previous stream is drained first (a rare, blocking event, no cost otherwise).
@@ -416,15 +450,15 @@ void batch::eval(int B, const void *dX, long ldx, void *dF, long ldf, void *dG, 
     // a handful of short trajectories (the SNOPT callback is B = 1): one launch, whole trajectory per
     // workgroup (measured per call: ts=100 24.7 vs 29.2 us, ts=200 29.7 vs 33.1 us; at ts=500, 8 waves
     // per workgroup, the tile-per-workgroup path is as fast, so the single form is used up to ts = 256)
-    static const bool no_single = std::getenv("TOLFG_NO_SINGLE_LAUNCH") != nullptr;
-    static const bool force_single = std::getenv("TOLFG_FORCE_SINGLE_LAUNCH") != nullptr;    // measurement: the one-workgroup form wherever it can run
-    const double out_bytes = (double)elem_size() * B * ((needF ? sz_.neF : 0) + (needG ? sz_.neG : 0));
+    const bool no_single = no_single_, force_single = force_single_;      // measurement build only (knobs.h)
+    // (the placement probe plans for the launch it stands in for, F + G, whatever it asks of this call: alloc_outputs)
+    const double out_bytes = plan_out_bytes_ > 0 ? plan_out_bytes_ : (double)elem_size() * B * ((needF ? sz_.neF : 0) + (needG ? sz_.neG : 0));
     // 16-byte window loads and defect stores need the rows of X and F on 16-byte boundaries; the slab stream
     // copes with any position of G (the waves shift their streams)
     const int vmax = dtype_ == TOLFG_F64 ? 2 : 4;
     const bool aligned = (reinterpret_cast<uintptr_t>(dX) % 16 == 0) && (ldx % vmax == 0) &&
                          (!needF || ((reinterpret_cast<uintptr_t>(dF) % 16 == 0) && (ldf % vmax == 0)));
-    const LaunchPlan lp = plan_launch(LaunchShape{B, a.N, dtype_, a.pattern, mission_, aligned ? 1 : 0, out_bytes, needG ? 1 : 0});
+    const LaunchPlan lp = plan_launch(LaunchShape{B, a.N, dtype_, a.pattern, mission_, aligned ? 1 : 0, out_bytes, needG ? 1 : 0, cus_});
     a.single = (!no_single && (lp.single || (force_single && B <= 8 && a.N <= 256 && mission_ != MISSION_MIXED))) ? 1 : 0;
     int max_nt = a.single ? 0 : (tile_nodes_forced_ > 0 ? tile_nodes_forced_ : lp.max_nt);
     if (!aligned && max_nt > 64) max_nt = 64;          // two nodes per lane (fp32 tiles beyond 64 nodes) need 16-byte rows
@@ -525,36 +559,18 @@ int batch::kernel_time(double *avg_ms, double *min_ms)
 void batch::x0_device(int B, void *dX, long ldx, hipStream_t stream)
 {
     if (B < 1 || B > ntraj_ || !dX || ldx < sz_.n) throw std::invalid_argument("x0_device: bad arguments");
-    if (!uploaded_) upload();
+    if (!uploaded_) upload(stream);          // also builds the per-(mission, node) table, once per batch object
     FgArgs a = args_;
     a.X = dX; a.ldx = ldx; a.traj = d_traj_; a.B = B;
-    const bool serial = std::getenv("TOLFG_X0_SERIAL") != nullptr;      // measurement / bitwise A/B: the serial reference form
-    if (!serial && !d_tgrid_) {
-        // node times exactly as InitialCond forms them: t = t + dt from 0 (ref: src/problemS10.cpp:60-64); the rest of
-        // the table (what a node's row holds for every trajectory of a mission alike) is computed on the device from
-        // them, once per batch object
-        const int N = sz_.N;
-        const size_t ld = (size_t)N + 1;
-        std::vector<double> tg(2 * (size_t)X0_FIELDS * ld, 0.0);
-        for (int m = 0; m < 2; ++m) {
-            const double dt = (m == 0 ? 20.0 : 10.0) / N;
-            double t = 0.0;
-            for (int k = 0; k <= N; ++k, t = t + dt) tg[(size_t)m * X0_FIELDS * ld + k] = t;
-        }
-        check(hipSetDevice(device_), "hipSetDevice");
-        check(hipMalloc(reinterpret_cast<void **>(&d_tgrid_), sizeof(double) * tg.size()), "hipMalloc(x0 table)");
-        check(hipMemcpy(d_tgrid_, tg.data(), sizeof(double) * tg.size(), hipMemcpyHostToDevice), "hipMemcpy(x0 table)");
-        check(launch_x0_table(d_tgrid_, N, mission_, stream), "launch x0 table");
-        check(hipStreamSynchronize(stream), "x0 table");      // later calls may come on other streams
-    }
-    check(launch_x0(a, mission_, dtype_, serial ? nullptr : d_tgrid_, stream), "launch x0");
+    // x0_serial_ (measurement build, bitwise A/B): the serial reference form, one thread per trajectory
+    check(launch_x0(a, mission_, dtype_, x0_serial_ ? nullptr : d_tgrid_, stream), "launch x0");
 }
 
 void batch::bounds_device(int B, void *dXlow, void *dXupp, long ldx, void *dFlow, void *dFupp, long ldf, hipStream_t stream)
 {
     if (B < 1 || B > ntraj_ || !dXlow || !dXupp || !dFlow || !dFupp || ldx < sz_.n || ldf < sz_.neF)
         throw std::invalid_argument("bounds_device: bad arguments");
-    if (!uploaded_) upload();
+    if (!uploaded_) upload(stream);
     BoundsArgs a{};
     a.xlow = dXlow; a.xupp = dXupp; a.ldx = ldx; a.Flow = dFlow; a.Fupp = dFupp; a.ldf = ldf;
     a.traj = d_traj_; a.B = B; a.N = sz_.N; a.mission = mission_;
@@ -585,14 +601,10 @@ void *batch::alloc_outputs(int B, int tries, long *ldg_out, double *probe_us, in
     const size_t bytes = elem_size() * (size_t)B * (size_t)ldg;
     if (ldg_out) *ldg_out = ldg;
     const double out_bytes = (double)elem_size() * B * ((double)sz_.neF + sz_.neG);
-    const LaunchPlan lp = plan_launch(LaunchShape{B, sz_.N, dtype_, args_.pattern, mission_, 1, out_bytes});
+    const LaunchPlan lp = plan_launch(LaunchShape{B, sz_.N, dtype_, args_.pattern, mission_, 1, out_bytes, 1, cus_ > 0 ? cus_ : 256});
     // placement matters to launches that stream beyond the cache (non-temporal form); the others take what they get
-    // measurement: TOLFG_PLACE_CAP moves the cap on the candidates (16), TOLFG_PLACE_EARLY sets the early-accept ratio (0.82; 0 = try them all)
-    int cap = 16;
-    double early = 0.82;
-    if (const char *e = std::getenv("TOLFG_PLACE_CAP")) { const int c = std::atoi(e); if (c >= 1 && c <= 64) cap = c; }
-    if (const char *e = std::getenv("TOLFG_PLACE_EARLY")) { const double r = std::atof(e); if (r >= 0.0 && r < 1.0) early = r; }
-    int n = (tries < 1 || !lp.nt_stores || lp.single) ? 1 : (tries > cap ? cap : tries);
+    const Knobs &kn = knobs();      // cap on the candidates (16) and early-accept ratio (0.82): fixed in the shipped library
+    int n = (tries < 1 || !lp.nt_stores || lp.single) ? 1 : (tries > kn.place_cap ? kn.place_cap : tries);
     if (n > 1) {      // the candidates are held side by side: never more than half of the device's free memory
         size_t free_b = 0, total_b = 0;
         check(hipSetDevice(device_), "hipSetDevice");
@@ -605,69 +617,85 @@ void *batch::alloc_outputs(int B, int tries, long *ldg_out, double *probe_us, in
     if (tried) *tried = n;
     if (n == 1) return device_alloc(device_, bytes);
     check(hipSetDevice(device_), "hipSetDevice");
-    hipStream_t stream = nullptr;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    check(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking), "hipStreamCreate");
     // Rejected candidates stay allocated until a choice is made: freed at once, their physical blocks would come straight back
     // as the next candidate.  The search ends early when a candidate is 18 % faster than the slowest seen: fast and slow class are
     // ~20 % apart (229 vs 285 us for the fp64 headline, 125 vs 157 for its fp32 form) with a middle one in between (259, 140).
-    std::vector<void *> held;
-    std::vector<double> held_us;
-    const bool was_store_shape = store_shape_;
-    const hipStream_t prev_stream = last_stream_;
-    const bool had_prev = have_last_stream_;
-    auto drop_all = [&] {
-        for (void *p : held) { try { device_free(p); } catch (const std::exception &) {} }
-        held.clear();
-    };
-    try {
-        check(hipEventCreate(&e0), "hipEventCreate");
-        check(hipEventCreate(&e1), "hipEventCreate");
-        store_shape_ = true;
-        double slowest = 0.0, fastest = 0.0;
-        for (int i = 0; i < n; ++i) {
+    // What the probe borrows from this object -- the store-shape switch, the planning size, the stream contract's "last stream"
+    // (the probe's private stream is gone afterwards) -- and what it creates is put back / destroyed on EVERY way out.
+    struct Probe {
+        batch &b;
+        bool was_store_shape, had_prev;
+        double was_plan_bytes;
+        hipStream_t prev_stream, stream = nullptr;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        std::vector<void *> held;
+        std::vector<double> held_us;
+        explicit Probe(batch &bb) : b(bb), was_store_shape(bb.store_shape_), had_prev(bb.have_last_stream_), was_plan_bytes(bb.plan_out_bytes_),
+                                    prev_stream(bb.last_stream_) {}
+        void drop(size_t keep) {
+            for (size_t i = 0; i < held.size(); ++i)
+                if (i != keep) { try { device_free(held[i]); } catch (const std::exception &) {} }
+            held.clear();
+        }
+        ~Probe() {
+            if (stream) (void)hipStreamSynchronize(stream);
+            b.store_shape_ = was_store_shape;
+            b.plan_out_bytes_ = was_plan_bytes;
+            b.last_stream_ = prev_stream;
+            b.have_last_stream_ = had_prev;
+            if (e0) (void)hipEventDestroy(e0);
+            if (e1) (void)hipEventDestroy(e1);
+            if (stream) (void)hipStreamDestroy(stream);
+            drop((size_t)-1);
+            clear_errors();
+        }
+    } pr(*this);
+    check(hipStreamCreateWithFlags(&pr.stream, hipStreamNonBlocking), "hipStreamCreate");
+    check(hipEventCreate(&pr.e0), "hipEventCreate");
+    check(hipEventCreate(&pr.e1), "hipEventCreate");
+    store_shape_ = true;
+    plan_out_bytes_ = out_bytes;       // the probe launches ask for G alone: they are planned as the F + G launch they stand in for
+    double slowest = 0.0, fastest = 0.0;
+    for (int i = 0; i < n; ++i) {
+        // a candidate that cannot be had (memory) or timed ends the search; the ones already timed stand
+        try {
+            if (i == kn.place_fail_at) throw hip_failure("device_alloc: injected failure (measurement build)");
             void *cand = device_alloc(device_, bytes);
-            held.push_back(cand);
+            pr.held.push_back(cand);
             // the bare store loop reads nothing but the trajectory table: G itself stands in for X
             auto run = [&](int reps) {
-                for (int r = 0; r < reps; ++r) eval(B, cand, ldg, nullptr, 0, cand, ldg, nullptr, 0, 1, stream);
+                for (int r = 0; r < reps; ++r) eval(B, cand, ldg, nullptr, 0, cand, ldg, nullptr, 0, 1, pr.stream);
             };
             run(3);
-            check(hipEventRecord(e0, stream), "hipEventRecord");
+            check(hipEventRecord(pr.e0, pr.stream), "hipEventRecord");
             run(10);
-            check(hipEventRecord(e1, stream), "hipEventRecord");
-            check(hipEventSynchronize(e1), "hipEventSynchronize");
+            check(hipEventRecord(pr.e1, pr.stream), "hipEventRecord");
+            check(hipEventSynchronize(pr.e1), "hipEventSynchronize");
             float ms = 0;
-            check(hipEventElapsedTime(&ms, e0, e1), "hipEventElapsedTime");
+            check(hipEventElapsedTime(&ms, pr.e0, pr.e1), "hipEventElapsedTime");
             const double us = 1e3 * ms / 10;
-            held_us.push_back(us);
+            pr.held_us.push_back(us);
             if (probe_us) probe_us[i] = us;
             if (us > slowest) slowest = us;
             if (fastest == 0.0 || us < fastest) fastest = us;
             if (tried) *tried = i + 1;
-            if (fastest < early * slowest) break;
+        } catch (const std::exception &) {
+            clear_errors();
+            if (pr.held_us.empty()) throw;            // not even one candidate: the caller hears why
+            if (pr.held.size() > pr.held_us.size()) {   // allocated but not timed: not a candidate
+                try { device_free(pr.held.back()); } catch (const std::exception &) {}
+                pr.held.pop_back();
+            }
+            break;
         }
-    } catch (...) {
-        store_shape_ = was_store_shape;
-        drop_all();
-        if (e0) (void)hipEventDestroy(e0);
-        if (e1) (void)hipEventDestroy(e1);
-        (void)hipStreamDestroy(stream);
-        throw;
+        if (fastest < kn.place_early * slowest) break;
     }
-    store_shape_ = was_store_shape;
-    check(hipStreamSynchronize(stream), "hipStreamSynchronize");
-    last_stream_ = prev_stream;            // the probe's private stream is gone: the stream contract resumes where it was
-    have_last_stream_ = had_prev;
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-    (void)hipStreamDestroy(stream);
+    check(hipStreamSynchronize(pr.stream), "hipStreamSynchronize");
     size_t ibest = 0;
-    for (size_t i = 1; i < held.size(); ++i)
-        if (held_us[i] < held_us[ibest]) ibest = i;
-    void *best = held[ibest];
-    held.erase(held.begin() + (long)ibest);
-    drop_all();
+    for (size_t i = 1; i < pr.held_us.size(); ++i)
+        if (pr.held_us[i] < pr.held_us[ibest]) ibest = i;
+    void *best = pr.held[ibest];
+    pr.drop(ibest);
     return best;
 }
 
@@ -718,11 +746,15 @@ void problem::ensure_device()
     // Device state is created by the first evaluation so that set-up (sizes, pattern, x0, bounds)
     // also works on a host without a GPU; evaluation itself has no CPU path.
     if (device_ready_) return;
-    if (const char *e = std::getenv("TOLFG_CALLBACK_STAGING")) zero_copy_ = !(e[0] == '1');
-    if (const char *e = std::getenv("TOLFG_ZERO_COPY_LIMIT")) zero_copy_limit_ = (size_t)std::atol(e);
-    if (const char *e = std::getenv("TOLFG_CHUNKS")) nchunks_ = std::min(kChunks, std::max(1, std::atoi(e)));
-    if (std::getenv("TOLFG_NO_REGISTER")) register_user_ = false;
-    if (std::getenv("TOLFG_NO_FLAG")) use_flag_ = false;
+    {   // measurement build only (knobs.h); the shipped library keeps the defaults of problem.h
+        const Knobs &kn = knobs();
+        if (kn.callback_staging) zero_copy_ = false;
+        if (kn.zero_copy_limit >= 0) zero_copy_limit_ = (size_t)kn.zero_copy_limit;
+        if (kn.chunks > 0) nchunks_ = std::min(kChunks, kn.chunks);
+        if (kn.no_register) register_user_ = false;
+        if (kn.no_flag) use_flag_ = false;
+        copy_x_ = kn.callback_copy_x;
+    }
     check(hipSetDevice(eng_->device()), "hipSetDevice");
     if (!stream_) check(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking), "hipStreamCreate");
     if (!hx_) check(hipHostMalloc(reinterpret_cast<void **>(&hx_), sizeof(double) * ldx_, hipHostMallocDefault), "hipHostMalloc");
@@ -764,7 +796,7 @@ void problem::set_wind_table(const double *wind_enu)
     const size_t bytes = sizeof(double) * 12 * (size_t)(eng_->sizes().N + 1);
     check(hipSetDevice(eng_->device()), "hipSetDevice");
     if (!dW_) check(hipMalloc(reinterpret_cast<void **>(&dW_), bytes), "hipMalloc(wind)");
-    check(hipMemcpy(dW_, wind_enu, bytes, hipMemcpyHostToDevice), "hipMemcpy(wind)");
+    blocking_upload(dW_, wind_enu, bytes, "upload(wind)");
     wind_host_.assign(wind_enu, wind_enu + 12 * (size_t)(eng_->sizes().N + 1));
     eng_->set_windmodel(TOLFG_WIND_TABLE);
     staged_ = false;
@@ -856,8 +888,7 @@ void problem::stage_and_launch(const double xin[], bool needF, bool needG, doubl
     // modelWind / computeF / computeG entry points (they compare against the copy), x goes through the pinned copy
     const bool direct = zero_copy_ && sizeof(double) * ((size_t)n + neF + neG) <= zero_copy_limit_;
     // (the window loads are 16 bytes wide and may touch element n of a row: only an x of even length is read in place)
-    static const bool copy_x = std::getenv("TOLFG_CALLBACK_COPY_X") != nullptr;       // measurement: always stage x
-    const void *vX = (caller_keeps_x && direct && ldx_ == n && !copy_x) ? device_view(const_cast<double *>(xin), sizeof(double) * n) : nullptr;
+    const void *vX = (caller_keeps_x && direct && ldx_ == n && !copy_x_) ? device_view(const_cast<double *>(xin), sizeof(double) * n) : nullptr;
     if (!vX) std::memcpy(hx_, xin, sizeof(double) * n);
     x_copied_ = vX == nullptr;
     void *vF = (needF && Fuser) ? device_view(Fuser, sizeof(double) * neF) : nullptr;
@@ -986,7 +1017,7 @@ void problem::evaluate(const double xin[], bool needF, double F[], bool needG, d
 {
     if (debug) { dump("Xoutput.txt", xin, n); dump_wind(xin); }
     if (!needF && !needG) return;
-    static const bool trace = std::getenv("TOLFG_TRACE") != nullptr;     // one line per call on stderr
+    static const bool trace = knobs().trace;     // one line per call on stderr
     if (trace) {
         using clk = std::chrono::steady_clock;
         const auto t0 = clk::now();

@@ -104,8 +104,13 @@ private:
     std::vector<limit> lm_;
     std::vector<snopt> sn_;
     int windmodel_, dtype_, device_;
-    void upload();
-    int waves_per_cu_ = 0;              // TOLFG_WAVES_PER_CU (measurements)
+    void upload(hipStream_t stream);    // trajectory table + x0 table, on `stream`, drained before it returns
+    int cus_ = 0;                       // compute units of device_ (asked once, at the first upload)
+    double plan_out_bytes_ = 0;         // > 0: eval() plans for this many output bytes (alloc_outputs' probe launches)
+    // The *_forced_ members below are measurement overrides of the launch plan: the shipped library never sets them, the
+    // measurement build (libtolfg_measure.so) takes them from the environment when the object is created (knobs.h)
+    bool no_single_ = false, force_single_ = false, x0_serial_ = false;
+    int waves_per_cu_ = 0;              // TOLFG_WAVES_PER_CU
     bool waves_forced_ = false;
     bool timing_ = false;
     bool store_shape_ = false;
@@ -206,8 +211,9 @@ private:
     struct HostView { void *base; size_t bytes; void *dev; int seen; };   // seen: 1 = once, 2 = registration tried
     std::vector<HostView> views_;
     bool persistent_arrays_ = false;                // tolfg_config.persistent_arrays
-    bool register_user_ = true;                     // TOLFG_NO_REGISTER=1 keeps the pinned staging copies
+    bool register_user_ = true;                     // TOLFG_NO_REGISTER=1 keeps the pinned staging copies (measurement build)
     bool use_flag_ = true;                          // TOLFG_NO_FLAG=1 synchronises the stream instead
+    bool copy_x_ = false;                           // TOLFG_CALLBACK_COPY_X=1 always stages x (measurement build)
     unsigned long long *done_ = nullptr;            // pinned, device-mapped completion word
     unsigned long long seq_ = 0;
     bool flagged_ = false;                          // the evaluation in flight reports through done_

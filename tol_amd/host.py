@@ -44,25 +44,26 @@ def _wind_grid(v, origin, spacing, datum):
 class _DeviceBlock:
     """Owner of a tolfg_device_alloc block, seen by torch through __cuda_array_interface__; freed with the last tensor."""
 
-    def __init__(self, ptr, shape, typestr):
+    def __init__(self, ptr, shape, typestr, L):
         self.ptr = ptr
+        self._L = L              # the library whose allocator made the block frees it
         self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (ptr, False), "version": 2}
 
     def __del__(self):
         try:
             if self.ptr:
-                lib().tolfg_device_free(C.c_void_p(self.ptr))
+                self._L.tolfg_device_free(C.c_void_p(self.ptr))
                 self.ptr = None
         except Exception:
             pass
 
 
-def _owned_tensor(ptr, shape, dtype, device):
+def _owned_tensor(ptr, shape, dtype, device, L):
     """A torch view of a tolfg_device_alloc block.  torch takes the device from the pointer's attributes; should it see the
     block anywhere else than on `device` it would hand back a COPY (and the placement would be lost without a word), so
     the pointer is checked and a mismatch is an error the caller can fall back from."""
     import torch
-    blk = _DeviceBlock(ptr, shape, "<f8" if dtype == "f64" else "<f4")
+    blk = _DeviceBlock(ptr, shape, "<f8" if dtype == "f64" else "<f4", L)
     t = torch.as_tensor(blk, device=torch.device("cuda", device))
     if t.data_ptr() != ptr or t.device.index != device:
         del t
@@ -70,14 +71,15 @@ def _owned_tensor(ptr, shape, dtype, device):
     return t
 
 
-def device_alloc(shape, dtype="f64", device=0):
+def device_alloc(shape, dtype="f64", device=0, library=None):
     """A device tensor [shape] in the library's placed form (tolfg_device_alloc); the tensor owns the memory."""
+    L = library or lib()
     n = 1
     for d in shape:
         n *= int(d)
     ptr = C.c_void_p()
-    check(lib().tolfg_device_alloc(int(device), n * (8 if dtype == "f64" else 4), C.byref(ptr)))
-    return _owned_tensor(ptr.value, tuple(int(d) for d in shape), dtype, device)
+    check(L.tolfg_device_alloc(int(device), n * (8 if dtype == "f64" else 4), C.byref(ptr)), L)
+    return _owned_tensor(ptr.value, tuple(int(d) for d in shape), dtype, device, L)
 
 
 class Problem:
@@ -86,8 +88,8 @@ class Problem:
     def __init__(self, mission, aircraft="tempest", east=0.0, north=0.0, up=100.0, east_goal=400.0,
                  north_goal=0.0, up_goal=70.0, radius_goal=100.0, ts=0, windmodel=capi.WIND_SHEAR,
                  Vref=2.4, href=10.0, start=(0.0, 0.0, 0.0), device=0, root_path=None, debug_dumps=False,
-                 pattern="reference", persistent_arrays=False):
-        L = lib()
+                 pattern="reference", persistent_arrays=False, library=None):
+        L = self._L = library or lib()
         cfg = Config()
         L.tolfg_config_default(C.byref(cfg))
         self._keep = (_enc(mission), _enc(aircraft), _enc(root_path))
@@ -100,15 +102,18 @@ class Problem:
         cfg.pattern = capi.PATTERNS[pattern]
         cfg.persistent_arrays = int(bool(persistent_arrays))
         self._h = C.c_void_p()
-        check(L.tolfg_create(C.byref(cfg), C.byref(self._h)))
+        self._rc(L.tolfg_create(C.byref(cfg), C.byref(self._h)))
         n, neF, neG = C.c_int(), C.c_int(), C.c_int()
-        check(L.tolfg_sizes(self._h, C.byref(n), C.byref(neF), C.byref(neG)))
+        self._rc(L.tolfg_sizes(self._h, C.byref(n), C.byref(neF), C.byref(neG)))
         self.n, self.neF, self.neG = n.value, neF.value, neG.value
         self.mission = mission
 
+    def _rc(self, rc):
+        return check(rc, self._L)
+
     def close(self):
         if getattr(self, "_h", None):
-            lib().tolfg_destroy(self._h)
+            self._L.tolfg_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -127,60 +132,60 @@ class Problem:
     def pattern(self):
         iG = np.zeros(self.neG, dtype=np.int32)
         jG = np.zeros(self.neG, dtype=np.int32)
-        check(lib().tolfg_pattern(self._h, _i(iG), _i(jG)))
+        self._rc(self._L.tolfg_pattern(self._h, _i(iG), _i(jG)))
         return iG, jG
 
     def x0(self):
         x = np.zeros(self.n)
-        check(lib().tolfg_x0(self._h, _d(x)))
+        self._rc(self._L.tolfg_x0(self._h, _d(x)))
         return x
 
     def bounds(self):
         xl, xu = np.zeros(self.n), np.zeros(self.n)
         Fl, Fu = np.zeros(self.neF), np.zeros(self.neF)
-        check(lib().tolfg_bounds(self._h, _d(xl), _d(xu), _d(Fl), _d(Fu)))
+        self._rc(self._L.tolfg_bounds(self._h, _d(xl), _d(xu), _d(Fl), _d(Fu)))
         return xl, xu, Fl, Fu
 
     def tolerances(self):
         a, b = C.c_double(), C.c_double()
-        check(lib().tolfg_tolerances(self._h, C.byref(a), C.byref(b)))
+        self._rc(self._L.tolfg_tolerances(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
     def set_wind_table(self, wind_enu):
         w = np.ascontiguousarray(wind_enu, dtype=np.float64)
-        check(lib().tolfg_set_wind_table(self._h, _d(w)))
+        self._rc(self._L.tolfg_set_wind_table(self._h, _d(w)))
 
     def set_wind_grid(self, v, origin, spacing=(150.0, 150.0, 150.0), datum=(0.0, 0.0, 0.0)):
         """Wind model 3: gridded north wind component v[nx][ny][nz] on a regular ENU grid."""
         g, keep = _wind_grid(v, origin, spacing, datum)
-        check(lib().tolfg_set_wind_grid(self._h, C.byref(g)))
+        self._rc(self._L.tolfg_set_wind_grid(self._h, C.byref(g)))
 
     def write_json(self, filename, x, final_cost):
         """ref: problem::writeJSON -- the `snopt_results.json` the mission glue and MATLAB tools read."""
         x = np.ascontiguousarray(x, dtype=np.float64)
-        check(lib().tolfg_write_json(self._h, _d(x), float(final_cost), str(filename).encode()))
+        self._rc(self._L.tolfg_write_json(self._h, _d(x), float(final_cost), str(filename).encode()))
 
     # ---- the callback, exactly as SNOPT enters it
     def make_current(self):
-        lib().tolfg_set_current(self._h)
+        self._L.tolfg_set_current(self._h)
 
     def handle_index(self):
-        return lib().tolfg_handle_index(self._h)
+        return self._L.tolfg_handle_index(self._h)
 
     # ---- arrays used in place (include/tolfg.h): the caller's promise that x / F / G stay where they are
     def register_arrays(self, x=None, F=None, G=None):
         """Pin and map these numpy arrays (float64, contiguous, 16-byte aligned) for the kernel to use in place whenever
         define_fg(..., F=F, G=G) passes exactly them; call forget_arrays() before letting go of them."""
         ptr = lambda a: None if a is None else _d(a)      # noqa: E731
-        check(lib().tolfg_register_arrays(self._h, ptr(x), ptr(F), ptr(G)))
+        self._rc(self._L.tolfg_register_arrays(self._h, ptr(x), ptr(F), ptr(G)))
 
     def forget_arrays(self):
-        check(lib().tolfg_forget_arrays(self._h))
+        self._rc(self._L.tolfg_forget_arrays(self._h))
 
     def registered_arrays(self):
-        k = lib().tolfg_registered_arrays(self._h)
+        k = self._L.tolfg_registered_arrays(self._h)
         if k < 0:
-            check(k)
+            self._rc(k)
         return k
 
     def define_fg(self, x, needF=True, needG=True, status=1, use_iu=False, F=None, G=None):
@@ -195,11 +200,11 @@ class Problem:
         if use_iu:
             iu = (C.c_int * 2)(capi.IU_MAGIC, self.handle_index())
             leniu = C.c_int(2)
-            lib().DEFINEGusrfg_(C.byref(st), C.byref(n), _d(x), C.byref(nf), C.byref(neF), _d(F), C.byref(ng),
+            self._L.DEFINEGusrfg_(C.byref(st), C.byref(n), _d(x), C.byref(nf), C.byref(neF), _d(F), C.byref(ng),
                                 C.byref(neG), _d(G), None, C.byref(zero), iu, C.byref(leniu), None, C.byref(zero))
         else:
             self.make_current()
-            lib().DEFINEGusrfg_(C.byref(st), C.byref(n), _d(x), C.byref(nf), C.byref(neF), _d(F), C.byref(ng),
+            self._L.DEFINEGusrfg_(C.byref(st), C.byref(n), _d(x), C.byref(nf), C.byref(neF), _d(F), C.byref(ng),
                                 C.byref(neG), _d(G), None, C.byref(zero), None, C.byref(zero), None, C.byref(zero))
         return F, G, st.value
 
@@ -211,27 +216,27 @@ class Problem:
         x = np.ascontiguousarray(x, dtype=np.float64)
         F, G = np.zeros(self.neF), np.zeros(self.neG)
         us = C.c_double()
-        st = lib().tolfg_time_callback_as(self._h, _d(x), _d(F), _d(G), int(needF), int(needG), int(bool(in_place)), int(warm), int(calls),
+        st = self._L.tolfg_time_callback_as(self._h, _d(x), _d(F), _d(G), int(needF), int(needG), int(bool(in_place)), int(warm), int(calls),
                                           C.byref(us))
         if st != 1:
-            check(st if st < 0 else capi.ERR_HIP)
+            self._rc(st if st < 0 else capi.ERR_HIP)
         return us.value, F, G
 
     # ---- the three methods the reference's callback dispatches to
     def modelWind(self, x):
         x = np.ascontiguousarray(x, dtype=np.float64)
-        check(lib().tolfg_modelWind(self._h, _d(x)))
+        self._rc(self._L.tolfg_modelWind(self._h, _d(x)))
 
     def computeF(self, x):
         x = np.ascontiguousarray(x, dtype=np.float64)
         F = np.zeros(self.neF)
-        check(lib().tolfg_computeF(self._h, _d(x), _d(F)))
+        self._rc(self._L.tolfg_computeF(self._h, _d(x), _d(F)))
         return F
 
     def computeG(self, x):
         x = np.ascontiguousarray(x, dtype=np.float64)
         G = np.zeros(self.neG)
-        check(lib().tolfg_computeG(self._h, _d(x), _d(G)))
+        self._rc(self._L.tolfg_computeG(self._h, _d(x), _d(G)))
         return G
 
 
@@ -255,8 +260,8 @@ class Batch:
     (the larger mission's) and sizes_of()/pattern(mission) give one mission's layout."""
 
     def __init__(self, mission, aircraft=("tempest",), ts=0, windmodel=capi.WIND_SHEAR, dtype="f64",
-                 device=0, root_path=None, pattern="reference"):
-        L = lib()
+                 device=0, root_path=None, pattern="reference", library=None):
+        L = self._L = library or lib()
         names = [a.encode() for a in aircraft]
         arr = (C.c_char_p * len(names))(*names)
         cfg = BatchConfig()
@@ -268,18 +273,21 @@ class Batch:
         cfg.device = int(device)
         cfg.pattern = capi.PATTERNS[pattern]
         self._h = C.c_void_p()
-        check(L.tolfg_batch_create(C.byref(cfg), C.byref(self._h)))
+        self._rc(L.tolfg_batch_create(C.byref(cfg), C.byref(self._h)))
         n, neF, neG = C.c_int(), C.c_int(), C.c_int()
-        check(L.tolfg_batch_sizes(self._h, C.byref(n), C.byref(neF), C.byref(neG)))
+        self._rc(L.tolfg_batch_sizes(self._h, C.byref(n), C.byref(neF), C.byref(neG)))
         self.n, self.neF, self.neG = n.value, neF.value, neG.value
         self.mission, self.dtype, self.device = mission, dtype, int(device)
         self.windmodel = windmodel
         self.B = 0
         self.missions = []
 
+    def _rc(self, rc):
+        return check(rc, self._L)
+
     def close(self):
         if getattr(self, "_h", None):
-            lib().tolfg_batch_destroy(self._h)
+            self._L.tolfg_batch_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -295,19 +303,19 @@ class Batch:
     def sizes_of(self, mission):
         """(n, neF, neG) of one mission of this batch."""
         n, neF, neG = C.c_int(), C.c_int(), C.c_int()
-        check(lib().tolfg_batch_mission_sizes(self._h, capi.MISSIONS[mission], C.byref(n), C.byref(neF), C.byref(neG)))
+        self._rc(self._L.tolfg_batch_mission_sizes(self._h, capi.MISSIONS[mission], C.byref(n), C.byref(neF), C.byref(neG)))
         return n.value, neF.value, neG.value
 
     def pattern(self, mission=None):
         if mission is None:
             iG = np.zeros(self.neG, dtype=np.int32)
             jG = np.zeros(self.neG, dtype=np.int32)
-            check(lib().tolfg_batch_pattern(self._h, _i(iG), _i(jG)))
+            self._rc(self._L.tolfg_batch_pattern(self._h, _i(iG), _i(jG)))
             return iG, jG
         neG = self.sizes_of(mission)[2]
         iG = np.zeros(neG, dtype=np.int32)
         jG = np.zeros(neG, dtype=np.int32)
-        check(lib().tolfg_batch_mission_pattern(self._h, capi.MISSIONS[mission], _i(iG), _i(jG)))
+        self._rc(self._L.tolfg_batch_mission_pattern(self._h, capi.MISSIONS[mission], _i(iG), _i(jG)))
         return iG, jG
 
     def set_trajectories(self, trajs):
@@ -318,17 +326,17 @@ class Batch:
             arr[t].mission = capi.MISSIONS[tr.mission] if self.mission == "mixed" else 0
             arr[t].north_goal, arr[t].east_goal, arr[t].radius_goal = tr.north_goal, tr.east_goal, tr.radius_goal
             arr[t].xi, arr[t].yi, arr[t].zi = tr.xi, tr.yi, tr.zi
-        check(lib().tolfg_batch_set_trajectories(self._h, len(trajs), arr))
+        self._rc(self._L.tolfg_batch_set_trajectories(self._h, len(trajs), arr))
         self.B = len(trajs)
 
     def set_wind_grid(self, v, origin, spacing=(150.0, 150.0, 150.0), datum=(0.0, 0.0, 0.0)):
         g, keep = _wind_grid(v, origin, spacing, datum)
-        check(lib().tolfg_batch_set_wind_grid(self._h, C.byref(g)))
+        self._rc(self._L.tolfg_batch_set_wind_grid(self._h, C.byref(g)))
         self.windmodel = capi.WIND_GRID
 
     def x0(self, t, zi=0.0):
         x = np.zeros(self.n)
-        check(lib().tolfg_batch_x0(self._h, int(t), float(zi), _d(x)))
+        self._rc(self._L.tolfg_batch_x0(self._h, int(t), float(zi), _d(x)))
         return x
 
     def bounds(self, t, zi=0.0):
@@ -337,7 +345,7 @@ class Batch:
         neF = self.sizes_of(self.missions[t])[1]
         xl, xu = np.zeros(self.n), np.zeros(self.n)
         Fl, Fu = np.zeros(neF), np.zeros(neF)
-        check(lib().tolfg_batch_bounds(self._h, int(t), float(zi), _d(xl), _d(xu), _d(Fl), _d(Fu)))
+        self._rc(self._L.tolfg_batch_bounds(self._h, int(t), float(zi), _d(xl), _d(xu), _d(Fl), _d(Fu)))
         return xl, xu, Fl, Fu
 
     # ---- device buffers (torch is plumbing: memory + streams)
@@ -378,11 +386,11 @@ class Batch:
         import torch
         ptr, ldg, tried = C.c_void_p(), C.c_long(), C.c_int()
         probe = (C.c_double * max(int(tries), 1))()
-        check(lib().tolfg_batch_alloc_outputs(self._h, int(B), int(tries), C.byref(ptr), C.byref(ldg), probe, C.byref(tried)))
+        self._rc(self._L.tolfg_batch_alloc_outputs(self._h, int(B), int(tries), C.byref(ptr), C.byref(ldg), probe, C.byref(tried)))
         self.placement = {"allocator": "tolfg_batch_alloc_outputs: one address range backed by 2 MiB physical chunks; best of the "
                                        "candidates by the bare store loop of the launch's own shape",
                           "candidates": tried.value, "probe_us": [round(probe[i], 2) for i in range(tried.value)] if tried.value > 1 else []}
-        return _owned_tensor(ptr.value, (int(B), ldg.value), self.dtype, self.device)
+        return _owned_tensor(ptr.value, (int(B), ldg.value), self.dtype, self.device, self._L)
 
     def _check(self, t, name, rows, cols):
         """The C ABI takes raw pointers and strides: a tensor of the wrong dtype, device or layout would
@@ -425,7 +433,7 @@ class Batch:
             stream = torch.cuda.current_stream(X.device).cuda_stream
         Fp, Fs = (F.data_ptr(), F.stride(0)) if needF else (None, 0)
         Gp, Gs = (G.data_ptr(), G.stride(0)) if needG else (None, 0)
-        check(lib().tolfg_batch_eval(self._h, int(B), X.data_ptr(), X.stride(0), Fp, Fs,
+        self._rc(self._L.tolfg_batch_eval(self._h, int(B), X.data_ptr(), X.stride(0), Fp, Fs,
                                      Gp, Gs, None if wind is None else wind.data_ptr(),
                                      int(needF), int(needG), None if obj is None else obj.data_ptr(),
                                      C.c_void_p(stream)))
@@ -437,7 +445,7 @@ class Batch:
         self._check(X, "X", B, self.n)
         if stream is None:
             stream = torch.cuda.current_stream(X.device).cuda_stream
-        check(lib().tolfg_batch_x0_device(self._h, int(B), X.data_ptr(), X.stride(0), C.c_void_p(stream)))
+        self._rc(self._L.tolfg_batch_x0_device(self._h, int(B), X.data_ptr(), X.stride(0), C.c_void_p(stream)))
 
     def bounds_device(self, xlow, xupp, Flow, Fupp, stream=None, B=None):
         import torch
@@ -448,7 +456,7 @@ class Batch:
             raise capi.TolfgError(capi.ERR_ARG, "xlow/xupp and Flow/Fupp must share their row strides")
         if stream is None:
             stream = torch.cuda.current_stream(xlow.device).cuda_stream
-        check(lib().tolfg_batch_bounds_device(self._h, int(B), xlow.data_ptr(), xupp.data_ptr(), xlow.stride(0),
+        self._rc(self._L.tolfg_batch_bounds_device(self._h, int(B), xlow.data_ptr(), xupp.data_ptr(), xlow.stride(0),
                                               Flow.data_ptr(), Fupp.data_ptr(), Flow.stride(0), C.c_void_p(stream)))
 
     def objectives(self, F, out=None, stream=None, B=None):
@@ -460,32 +468,32 @@ class Batch:
         self._check(out, "out", B, None)
         if stream is None:
             stream = torch.cuda.current_stream(F.device).cuda_stream
-        check(lib().tolfg_batch_objectives(self._h, int(B), F.data_ptr(), F.stride(0), out.data_ptr(),
+        self._rc(self._L.tolfg_batch_objectives(self._h, int(B), F.data_ptr(), F.stride(0), out.data_ptr(),
                                            C.c_void_p(stream)))
         return out
 
     def status(self):
         """Raises TolfgError(ERR_HIP) when an evaluation since the last call lost an objective partial (ask after the
         evaluations have completed, e.g. after torch.cuda.synchronize())."""
-        check(lib().tolfg_batch_status(self._h))
+        self._rc(self._L.tolfg_batch_status(self._h))
 
     def set_timing(self, on=True):
-        check(lib().tolfg_batch_set_timing(self._h, int(bool(on))))
+        self._rc(self._L.tolfg_batch_set_timing(self._h, int(bool(on))))
 
     def set_store_shape(self, on=True):
         """Measurement aid: while on, eval() launches the bare store loop of its own launch shape (F, G: garbage)."""
-        check(lib().tolfg_batch_set_store_shape(self._h, int(bool(on))))
+        self._rc(self._L.tolfg_batch_set_store_shape(self._h, int(bool(on))))
 
     def kernel_time(self):
         """(launches, avg_ms, min_ms) of fg_kernel since the last call (HIP events on the launch stream)."""
         a, m = C.c_double(), C.c_double()
-        n = lib().tolfg_batch_kernel_time(self._h, C.byref(a), C.byref(m))
+        n = self._L.tolfg_batch_kernel_time(self._h, C.byref(a), C.byref(m))
         if n < 0:
-            check(n)
+            self._rc(n)
         return n, a.value, m.value
 
     def algorithmic_bytes(self, B=None):
-        return lib().tolfg_batch_algorithmic_bytes(self._h, int(self.B if B is None else B))
+        return self._L.tolfg_batch_algorithmic_bytes(self._h, int(self.B if B is None else B))
 
 
 class Multi:
@@ -494,8 +502,8 @@ class Multi:
     G to the host (tests, small batches)."""
 
     def __init__(self, mission, aircraft=("tempest",), ts=0, windmodel=capi.WIND_SHEAR, dtype="f64", devices=(0,),
-                 root_path=None, pattern="reference"):
-        L = lib()
+                 root_path=None, pattern="reference", library=None):
+        L = self._L = library or lib()
         names = [a.encode() for a in aircraft]
         arr = (C.c_char_p * len(names))(*names)
         cfg = BatchConfig()
@@ -508,16 +516,19 @@ class Multi:
         cfg.pattern = capi.PATTERNS[pattern]
         devs = (C.c_int * len(devices))(*[int(d) for d in devices])
         self._h = C.c_void_p()
-        check(L.tolfg_multi_create(C.byref(cfg), devs, len(devices), C.byref(self._h)))
+        self._rc(L.tolfg_multi_create(C.byref(cfg), devs, len(devices), C.byref(self._h)))
         n, neF, neG = C.c_int(), C.c_int(), C.c_int()
-        check(L.tolfg_multi_sizes(self._h, C.byref(n), C.byref(neF), C.byref(neG)))
+        self._rc(L.tolfg_multi_sizes(self._h, C.byref(n), C.byref(neF), C.byref(neG)))
         self.n, self.neF, self.neG = n.value, neF.value, neG.value
         self.mission, self.dtype, self.devices = mission, dtype, tuple(int(d) for d in devices)
         self.total = 0
 
+    def _rc(self, rc):
+        return check(rc, self._L)
+
     def close(self):
         if getattr(self, "_h", None):
-            lib().tolfg_multi_destroy(self._h)
+            self._L.tolfg_multi_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -527,7 +538,7 @@ class Multi:
             pass
 
     def rccl_library(self):
-        return lib().tolfg_multi_rccl_library().decode()
+        return self._L.tolfg_multi_rccl_library().decode()
 
     def set_trajectories(self, trajs):
         arr = (Traj * len(trajs))()
@@ -536,17 +547,17 @@ class Multi:
             arr[t].mission = capi.MISSIONS[tr.mission] if self.mission == "mixed" else 0
             arr[t].north_goal, arr[t].east_goal, arr[t].radius_goal = tr.north_goal, tr.east_goal, tr.radius_goal
             arr[t].xi, arr[t].yi, arr[t].zi = tr.xi, tr.yi, tr.zi
-        check(lib().tolfg_multi_set_trajectories(self._h, len(trajs), arr))
+        self._rc(self._L.tolfg_multi_set_trajectories(self._h, len(trajs), arr))
         self.total = len(trajs)
 
     def shard(self, i):
         lo, hi = C.c_long(), C.c_long()
-        check(lib().tolfg_multi_shard(self._h, int(i), C.byref(lo), C.byref(hi)))
+        self._rc(self._L.tolfg_multi_shard(self._h, int(i), C.byref(lo), C.byref(hi)))
         return lo.value, hi.value
 
     def set_wind_grid(self, v, origin, spacing=(150.0, 150.0, 150.0), datum=(0.0, 0.0, 0.0)):
         g, keep = _wind_grid(v, origin, spacing, datum)
-        check(lib().tolfg_multi_set_wind_grid(self._h, C.byref(g)))
+        self._rc(self._L.tolfg_multi_set_wind_grid(self._h, C.byref(g)))
 
     def set_wind_tables(self, wind_enu):
         """wind_enu: [total][12][ts+1], the table of every trajectory in global order (batch created with WIND_TABLE)."""
@@ -554,33 +565,99 @@ class Multi:
         N = (self.n - 1) // 11 - 1
         if w.shape != (self.total, 12, N + 1):
             raise capi.TolfgError(capi.ERR_ARG, f"wind tables must be [{self.total}][12][{N + 1}], got {w.shape}")
-        check(lib().tolfg_multi_set_wind_tables(self._h, _d(w)))
+        self._rc(self._L.tolfg_multi_set_wind_tables(self._h, _d(w)))
 
     def x0(self):
-        check(lib().tolfg_multi_x0(self._h))
+        self._rc(self._L.tolfg_multi_x0(self._h))
 
     def eval(self, needF=True, needG=True):
-        check(lib().tolfg_multi_eval(self._h, int(needF), int(needG)))
+        self._rc(self._L.tolfg_multi_eval(self._h, int(needF), int(needG)))
 
     def gather_objectives(self):
         out = np.zeros(self.total, dtype=np.float64 if self.dtype == "f64" else np.float32)
-        check(lib().tolfg_multi_gather_objectives(self._h, out.ctypes.data))
+        self._rc(self._L.tolfg_multi_gather_objectives(self._h, out.ctypes.data))
         return out
+
+    # ---- the asynchronous form: evaluations run beside the gathers of the ones before them
+    def _xptrs(self, dX):
+        if dX is None:
+            return None, 0
+        if len(dX) != len(self.devices):
+            raise capi.TolfgError(capi.ERR_ARG, "one X pointer per device is required")
+        return (C.c_void_p * len(dX))(*[int(p) for p in dX]), len(dX)
+
+    def eval_from(self, dX, needF=True, needG=True):
+        """One evaluation, device i reading its shard's x rows from the device pointer dX[i] (row stride as buffers(i))."""
+        arr, n = self._xptrs(dX)
+        self._rc(self._L.tolfg_multi_eval_from(self._h, arr, n, int(needF), int(needG)))
+
+    def gather_begin(self):
+        t = C.c_ulong()
+        self._rc(self._L.tolfg_multi_gather_begin(self._h, C.byref(t)))
+        return t.value
+
+    def gather_wait(self, ticket, want=True):
+        out = np.zeros(self.total, dtype=np.float64 if self.dtype == "f64" else np.float32) if want else None
+        self._rc(self._L.tolfg_multi_gather_wait(self._h, int(ticket), None if out is None else out.ctypes.data))
+        return out
+
+    def step(self, dX=None, needG=True):
+        """eval (F always) + gather_begin; returns the gather's ticket."""
+        arr, n = self._xptrs(dX)
+        t = C.c_ulong()
+        self._rc(self._L.tolfg_multi_step(self._h, arr, n, int(needG), C.byref(t)))
+        return t.value
+
+    def set_issue(self, mode):
+        """'grouped' (one ncclGroupStart/End bracket from the caller's thread) | 'threads' (every device's thread calls for
+        its own communicator)."""
+        self._rc(self._L.tolfg_multi_set_issue(self._h, {"grouped": capi.ISSUE_GROUPED, "threads": capi.ISSUE_THREADS}[mode]))
+
+    def set_placement(self, tries):
+        self._rc(self._L.tolfg_multi_set_placement(self._h, int(tries)))
+
+    def buffers(self, i):
+        """((dX, ldx), (dF, ldf), (dG, ldg)) of shard i: device pointers (ints) on devices[i] and row strides in elements."""
+        dX, dF, dG = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        ldx, ldf, ldg = C.c_long(), C.c_long(), C.c_long()
+        self._rc(self._L.tolfg_multi_buffers(self._h, int(i), C.byref(dX), C.byref(ldx), C.byref(dF), C.byref(ldf), C.byref(dG), C.byref(ldg)))
+        return (dX.value, ldx.value), (dF.value, ldf.value), (dG.value, ldg.value)
+
+    def time_steps(self, steps, warm=10, x_sets=None, needF=True, needG=True, gather=True):
+        """The native step loop (tolfg_multi_time_steps).  x_sets: a list of per-device pointer lists used in rotation, or
+        None for the library's own X.  Returns a dict of the timings (us) and the per-device launch times."""
+        nd = len(self.devices)
+        n_x = 0 if not x_sets else len(x_sets)
+        arr = None
+        if n_x:
+            flat = [int(p) for xs in x_sets for p in xs]
+            if len(flat) != n_x * nd:
+                raise capi.TolfgError(capi.ERR_ARG, "every X set needs one pointer per device")
+            arr = (C.c_void_p * len(flat))(*flat)
+        t = capi.MultiTiming()
+        per = (C.c_double * nd)()
+        self._rc(self._L.tolfg_multi_time_steps(self._h, n_x, arr, int(needF), int(needG), int(gather), int(warm), int(steps), C.byref(t), per))
+        return {"wall_us_per_step": t.wall_us_per_step, "launch_us_per_step": t.launch_us_per_step, "issue_us_per_step": t.issue_us_per_step,
+                "gather_us": t.gather_us, "devices": t.devices, "steps": t.steps, "issue": ("grouped", "threads")[t.issue],
+                "launch_us_per_device": [per[i] for i in range(nd)]}
+
+    def rccl_version(self):
+        return self._L.tolfg_multi_rccl_version()
 
     def mean_objective(self):
         m = C.c_double()
-        check(lib().tolfg_multi_mean_objective(self._h, C.byref(m)))
+        self._rc(self._L.tolfg_multi_mean_objective(self._h, C.byref(m)))
         return m.value
 
     def sync(self):
-        check(lib().tolfg_multi_sync(self._h))
+        self._rc(self._L.tolfg_multi_sync(self._h))
 
     def fetch(self, i, with_x=False):
         """(F, G) -- with_x: (X, F, G) -- of shard i as host arrays [rows][ld] (device-to-host copies with the HIP runtime
         the library uses)."""
         dX, dF, dG = C.c_void_p(), C.c_void_p(), C.c_void_p()
         ldx, ldf, ldg = C.c_long(), C.c_long(), C.c_long()
-        check(lib().tolfg_multi_buffers(self._h, int(i), C.byref(dX), C.byref(ldx), C.byref(dF), C.byref(ldf), C.byref(dG), C.byref(ldg)))
+        self._rc(self._L.tolfg_multi_buffers(self._h, int(i), C.byref(dX), C.byref(ldx), C.byref(dF), C.byref(ldf), C.byref(dG), C.byref(ldg)))
         self.sync()
         lo, hi = self.shard(i)
         dt = np.float64 if self.dtype == "f64" else np.float32

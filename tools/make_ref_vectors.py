@@ -25,6 +25,8 @@ usage: python tools/make_ref_vectors.py                   (writes tests/golden/r
                                                            shipped -- both missions x all five air frames at ts = 100, and
                                                            ts = 200 once per mission -- countG included; ~9 min on 6 cores)
        python tools/make_ref_vectors.py --set long        (writes tests/golden/ref_eval_long.npz: S10 / skywalker / ts = 2000)
+       python tools/make_ref_vectors.py --set json-keys   (writes tests/golden/results_json_keys.json: the key names the reference's
+                                                           result writer assigns, src/problem.cpp writeJSON)
 """
 import math
 import os
@@ -367,14 +369,51 @@ SHIPPED = [(m, 100, a, (400.0, 0.0, 70.0, 100.0 if m == "S10" else 0.0), (0.0, 0
           [("S10", 200, "tempest", (400.0, 0.0, 70.0, 100.0), (0.0, 0.0, 0.0)), ("G7", 200, "tempest", (400.0, 0.0, 70.0, 0.0), (0.0, 0.0, 0.0))]
 
 
+def json_keys():
+    """The key names the reference's result writer assigns (problem::writeJSON, src/problem.cpp:1247-1365: statements of the form
+    snopt_results["a"]["b"] = ...;), read from its text at fixture time.  Stored as names only: tests/golden/results_json_keys.json."""
+    import json
+    import re
+    ref = os.environ.get("TOL_REFERENCE", "/root/reference")
+    with open(os.path.join(ref, "src", "problem.cpp")) as fh:
+        text = fh.read()
+    start = text.index("problem::writeJSON")
+    end = text.index("problem::writeTXT", start)
+    first = text.count("\n", 0, start) + 1
+    last = text.count("\n", 0, end) + 1
+    keys = {"top": []}
+    var = None
+    for stmt in re.finditer(r'^\s*(\w+)((?:\s*\[\s*"[^"]+"\s*\])+)\s*=[^=]', text[start:end], flags=re.M):
+        path = re.findall(r'"([^"]+)"', stmt.group(2))
+        var = var or stmt.group(1)
+        if stmt.group(1) != var:
+            continue
+        if path[0] not in keys["top"]:
+            keys["top"].append(path[0])
+        if len(path) == 2:
+            keys.setdefault(path[0], [])
+            if path[1] not in keys[path[0]]:
+                keys[path[0]].append(path[1])
+        elif len(path) > 2:
+            raise SystemExit("deeper nesting than the extractor knows: %r" % (path,))
+    out = {"source": "src/problem.cpp:%d-%d (problem::writeJSON), assignments to %s[...]" % (first, last, var), "keys": keys}
+    path = os.environ.get("REF_VECTORS_OUT") or os.path.join(os.path.dirname(HERE), "tests", "golden", "results_json_keys.json")
+    with open(path, "w") as fh:
+        json.dump(out, fh, indent=1, sort_keys=True)
+        fh.write("\n")
+    print("wrote", path, {k: len(v) for k, v in keys.items()})
+
+
 def main():
     import argparse
     import multiprocessing as mp
     ap = argparse.ArgumentParser()
-    ap.add_argument("--set", choices=["small", "shipped", "long"], default="small")
+    ap.add_argument("--set", choices=["small", "shipped", "long", "json-keys"], default="small")
     ap.add_argument("--workers", type=int, default=6)
     args = ap.parse_args()
     t_start = time.time()
+    if args.set == "json-keys":
+        return json_keys()
     if args.set == "long":
         tag, out = run_long(dict(tag="l0_", mission="S10", N=2000, airframe="skywalker", goal=(400.0, 0.0, 70.0, 100.0), start=(0.0, 0.0, 0.0)))
         out["cases"] = np.array([tag])
