@@ -5,6 +5,8 @@
 # tol_amd/csrc/plan.cpp were obtained, not product tooling (tools/README.md).  Round-2 entries expect the round-2 harness arguments.
 # (The bodies are not indented: several hold here-documents.)
 name=${1:-list}
+# the TOLFG_* switches these experiments set exist in the measurement build only (tol_amd/csrc/knobs.h; round 5)
+export TOLFG_LIBRARY=${TOLFG_LIBRARY:-$PWD/tol_amd/lib/libtolfg_measure.so}
 case "$name" in
 r02a)
 # round-2 experiment A (one gpurun call): write-stream shapes, tile size x cap x fused sweep, callback trace
@@ -280,12 +282,12 @@ r02e)
 mkdir -p gpurun_out/r02e
 O=gpurun_out/r02e
 timeout -k 10 300 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; echo "pytest exit $?"; tail -5 $O/pytest_gpu.log
-echo "== default (flag + registered arrays)"; timeout -k 10 120 python tools/callback_rate.py 2>&1 | tail -6
-echo "== TOLFG_NO_FLAG"; TOLFG_NO_FLAG=1 timeout -k 10 120 python tools/callback_rate.py 2>&1 | tail -6
-echo "== TOLFG_NO_REGISTER"; TOLFG_NO_REGISTER=1 timeout -k 10 120 python tools/callback_rate.py 2>&1 | tail -6
-echo "== TOLFG_NO_FLAG TOLFG_NO_REGISTER (round-1 behaviour)"; TOLFG_NO_FLAG=1 TOLFG_NO_REGISTER=1 timeout -k 10 120 python tools/callback_rate.py 2>&1 | tail -6
-echo "== zero-copy limit 4 MB (ts=2000 direct)"; TOLFG_ZERO_COPY_LIMIT=4000000 timeout -k 10 120 python tools/callback_rate.py 2>&1 | tail -6
-echo "== zero-copy limit 4 MB, nt stores"; TOLFG_NT_STORES=1 TOLFG_ZERO_COPY_LIMIT=4000000 timeout -k 10 120 python tools/callback_rate.py 2>&1 | tail -6
+echo "== default (flag + registered arrays)"; timeout -k 10 120 python tools/callback_tool.py rate 2>&1 | tail -6
+echo "== TOLFG_NO_FLAG"; TOLFG_NO_FLAG=1 timeout -k 10 120 python tools/callback_tool.py rate 2>&1 | tail -6
+echo "== TOLFG_NO_REGISTER"; TOLFG_NO_REGISTER=1 timeout -k 10 120 python tools/callback_tool.py rate 2>&1 | tail -6
+echo "== TOLFG_NO_FLAG TOLFG_NO_REGISTER (round-1 behaviour)"; TOLFG_NO_FLAG=1 TOLFG_NO_REGISTER=1 timeout -k 10 120 python tools/callback_tool.py rate 2>&1 | tail -6
+echo "== zero-copy limit 4 MB (ts=2000 direct)"; TOLFG_ZERO_COPY_LIMIT=4000000 timeout -k 10 120 python tools/callback_tool.py rate 2>&1 | tail -6
+echo "== zero-copy limit 4 MB, nt stores"; TOLFG_NT_STORES=1 TOLFG_ZERO_COPY_LIMIT=4000000 timeout -k 10 120 python tools/callback_tool.py rate 2>&1 | tail -6
 echo "== trace"; timeout -k 10 120 python tools/trace_callback.py > $O/trace.out 2> $O/trace.err; grep -A4 -- "---" $O/trace.err | grep -v amdgpu.ids | head -40
 ;;
 r02f)
@@ -293,8 +295,8 @@ r02f)
 mkdir -p gpurun_out/r02f
 O=gpurun_out/r02f
 timeout -k 10 400 python -m pytest tests -m gpu -x -q -s > $O/pytest_gpu.log 2>&1; echo "pytest exit $?"; tail -15 $O/pytest_gpu.log | cut -c1-300
-echo "== callback (default)"; timeout -k 10 120 python tools/callback_rate.py 2>&1 | tail -5
-echo "== callback TOLFG_NO_FLAG"; TOLFG_NO_FLAG=1 timeout -k 10 120 python tools/callback_rate.py 2>&1 | tail -5
+echo "== callback (default)"; timeout -k 10 120 python tools/callback_tool.py rate 2>&1 | tail -5
+echo "== callback TOLFG_NO_FLAG"; TOLFG_NO_FLAG=1 timeout -k 10 120 python tools/callback_tool.py rate 2>&1 | tail -5
 timeout -k 10 300 tools/bin/fgbench reps=40 nt=1 xcd=1 \
   4096,200,64,7,1,1 4096,200,64,7,1,2 8192,200,64,7,1,2 \
   4096,200,64,8,1,1,1 4096,200,64,12,1,1,1 8192,200,64,8,1,2,1 8192,200,64,12,1,2,1 8192,200,64,8,1,0,1 \
@@ -307,7 +309,7 @@ mkdir -p gpurun_out/r02g
 O=gpurun_out/r02g
 timeout -k 10 600 python -m pytest tests -m gpu -x -q -s > $O/pytest_gpu.log 2>&1; echo "pytest exit $?"; tail -12 $O/pytest_gpu.log | cut -c1-400
 grep "worst scaled error per class" $O/pytest_gpu.log | cut -c1-1200
-echo "== callback (default)"; timeout -k 10 120 python tools/callback_rate.py 2>&1 | tail -5
+echo "== callback (default)"; timeout -k 10 120 python tools/callback_tool.py rate 2>&1 | tail -5
 timeout -k 10 500 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench exit $?"; tail -3 $O/bench.err; python - <<'PY'
 import json
 d=json.loads(open('gpurun_out/r02g/bench.json').read().strip().splitlines()[-1])
@@ -322,7 +324,7 @@ r02h)
 mkdir -p gpurun_out/r02h
 O=gpurun_out/r02h
 timeout -k 10 600 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; echo "pytest exit $?"; tail -6 $O/pytest_gpu.log | cut -c1-400
-echo "== callback (default)"; timeout -k 10 120 python tools/callback_rate.py 2 2>&1 | tail -10
+echo "== callback (default)"; timeout -k 10 120 python tools/callback_tool.py rate 2 2>&1 | tail -10
 timeout -k 10 400 tools/bin/fgbench reps=40 nt=1 xcd=1 \
   4096,200,64,8,1 4096,200,32,12,1 4096,200,32,0,1 4096,200,16,0,1 4096,200,16,16,1 4096,200,8,0,1 \
   nt=0 1024,200,64,0,1 1024,200,32,0,1 1024,200,16,0,1 512,200,64,0,1 512,200,32,0,1 512,200,16,0,1 128,200,64,0,1 128,200,32,0,1 128,200,16,0,1 128,200,8,0,1 \
@@ -338,7 +340,7 @@ r02i)
 mkdir -p gpurun_out/r02i
 O=gpurun_out/r02i
 timeout -k 10 600 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; echo "pytest exit $?"; tail -4 $O/pytest_gpu.log | cut -c1-400
-echo "== callback"; timeout -k 10 120 python tools/callback_rate.py 2>&1 | tail -5
+echo "== callback"; timeout -k 10 120 python tools/callback_tool.py rate 2>&1 | tail -5
 timeout -k 10 500 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench exit $?"; tail -2 $O/bench.err
 python tools/show_bench.py $O/bench.json
 timeout -k 10 600 bash tools/profile_gpu.sh r02 > $O/profile.log 2>&1; echo "profile exit $?"; tail -3 $O/profile.log
@@ -862,12 +864,12 @@ r04_callback_tiles)
 # Run on the GPU box from the repo root.
 for rep in 1 2; do
 echo "== pass $rep: one workgroup per trajectory (TOLFG_FORCE_SINGLE_LAUNCH=1)"
-TOLFG_FORCE_SINGLE_LAUNCH=1 python3 tools/callback_rate.py | grep " 200 \| 100 "
+TOLFG_FORCE_SINGLE_LAUNCH=1 python3 tools/callback_tool.py rate | grep " 200 \| 100 "
 echo "== pass $rep: the plan (5 tiles from ts = 100)"
-python3 tools/callback_rate.py | grep " 200 \| 100 "
+python3 tools/callback_tool.py rate | grep " 200 \| 100 "
 for nt in 52 32 28; do
     echo "== pass $rep: tile-per-workgroup, TOLFG_TILE_NODES=$nt"
-    TOLFG_NO_SINGLE_LAUNCH=1 TOLFG_TILE_NODES=$nt python3 tools/callback_rate.py | grep " 200 \| 100 "
+    TOLFG_NO_SINGLE_LAUNCH=1 TOLFG_TILE_NODES=$nt python3 tools/callback_tool.py rate | grep " 200 \| 100 "
 done
 done
 ;;

@@ -143,3 +143,26 @@ def test_a_candidate_that_cannot_be_had_ends_the_search_and_leaves_the_batch_usa
     assert torch.equal(G[:, :bt.neG], G0[:, :bt.neG]) and torch.equal(F[:, :bt.neF], F0[:, :bt.neF])
     bt.status()
     bt.close()
+
+
+@pytest.mark.gpu
+def test_a_write_that_follows_the_allocation_at_once_survives(tolfg):
+    """Round 5: the driver wipes VRAM it gets back with a job of its own and hands the chunks out again before that job has run; a
+    block from hipMemCreate that follows a free was seen to go back to 0.0, chunk by chunk, milliseconds AFTER a kernel had filled it
+    (40-90 % of back-to-back allocations with round 4's allocator: tools/placed_fresh_write.py, profiles/r05_fresh_vmm_blocks.md).
+    tolfg_device_alloc now settles a block before it hands it out.  Allocate, fill at once, look, look again, free -- back to back."""
+    import time
+    import torch
+    lost = []
+    for count in (1, 1 << 20, 8 << 20):
+        for i in range(40 if count < (8 << 20) else 12):
+            t = tolfg.device_alloc((count,), "f64")
+            t.fill_(1.0 + i)
+            torch.cuda.synchronize()
+            a = int((t != 1.0 + i).sum())
+            time.sleep(0.004)
+            b = int((t != 1.0 + i).sum())
+            if a or b:
+                lost.append((count, i, a, b))
+            del t
+    assert not lost, lost

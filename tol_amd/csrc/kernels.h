@@ -162,6 +162,9 @@ struct BoundsArgs {
 };
 hipError_t launch_bounds(const BoundsArgs &a, int dtype, hipStream_t s);
 
+// *count += the number of 32-bit words in [p, p + bytes) that differ from `pattern` (alloc_kernels.hip; device_alloc's settle check)
+hipError_t launch_count_not(const void *p, size_t bytes, unsigned pattern, unsigned long long *count, hipStream_t s);
+
 // LDS bytes per workgroup of the fg kernel (for DESIGN.md / occupancy reporting)
 int fg_lds_bytes(int dtype, int nt = 0, int sub_nodes = 0);        // nt = nodes per tile (0 = 64); sub_nodes: FgArgs::sub_nodes
 // LDS bytes to request at launch so that at most waves_per_cu workgroups share a CU (0 = no cap)

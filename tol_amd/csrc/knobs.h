@@ -28,6 +28,8 @@
 //     TOLFG_PLACE_EARLY=0..1          its early-accept ratio (0.82; 0 = try them all)
 //     TOLFG_PLACED_CHUNK_KIB=64..2^20 physical chunk of device_alloc (2048)
 //     TOLFG_PLACE_FAIL_AT=i           fault injection: candidate i (0-based) of alloc_outputs fails to allocate
+//     TOLFG_PLACE_SETTLE=0|1          0 = device_alloc hands a fresh block out at once (round 4's form: the driver's pending wipe may
+//                                     zero what is written to it); 1 = it settles the block first (problem.cpp: settle_block)
 //     TOLFG_CALLBACK_STAGING=1        the callback through explicit H2D / D2H copies instead of host-mapped arrays
 //     TOLFG_ZERO_COPY_LIMIT=bytes     size of x+F+G up to which the callback addresses host memory directly
 //     TOLFG_CHUNKS=1..6               pieces of G's device-to-host copy on the staged path
@@ -58,6 +60,7 @@ struct Knobs {
     double place_early = 0.82;
     size_t placed_chunk = 2u << 20;
     int  place_fail_at = -1;
+    int  place_settle = 1;
     bool callback_staging = false;
     long zero_copy_limit = -1;       // -1 = the library's (64 MB)
     int  chunks = -1;                // -1 = the library's (2)

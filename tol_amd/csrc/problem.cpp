@@ -11,6 +11,7 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <thread>
 
 #include <hip/hip_runtime_api.h>
 
@@ -103,6 +104,7 @@ struct DeviceBlock {
 };
 std::mutex g_blocks_mu;
 std::map<void *, DeviceBlock> g_blocks;
+void note_freed(size_t bytes);       // settle_block's bookkeeping, below
 
 void release_block(void *ptr, DeviceBlock &b)
 {
@@ -113,7 +115,71 @@ void release_block(void *ptr, DeviceBlock &b)
     (void)hipMemUnmap(ptr, b.bytes);
     for (hipMemGenericAllocationHandle_t h : b.handles) (void)hipMemRelease(h);
     (void)hipMemAddressFree(ptr, b.bytes);
+    note_freed(b.bytes);          // the driver wipes what it gets back, later: the next device_alloc waits accordingly (settle_block)
 }
+}  // namespace
+
+namespace {
+
+// A block that hipMemCreate has just produced is NOT yet the caller's to write.  The driver wipes VRAM it gets back with a copy-engine
+// job of its own, hands the chunks out again before that job has run, and neither hipMemMap nor hipMemSetAccess waits for it: measured
+// on MI355X / ROCm 7.2 (tools/placed_fresh_write.py, profiles/r05_fresh_vmm_blocks.md), a kernel that fills an 8 MB block right after
+// device_alloc finds up to whole 2 MiB chunks back at 0.0 a few milliseconds later in ~50 % of allocations that follow a free -- silently.
+// Zeroing the block first does not help, waiting for the chunks' fences through a dma-buf poll does not either, blocks allocated
+// without a free before them are (all but) safe, and hipMalloc never shows it.  So the allocator settles a block before it hands it
+// out: the block is filled with a pattern and must still hold it, every word, through a quiet period -- what a copy engine at a
+// conservative 10 GB/s needs for this block plus everything this library freed during the last second, at least 1 ms; a word that
+// went back to zero restarts the wait.  450 back-to-back allocations after frees: none lost a write (against 40-90 % without).
+// Cost: one fill and a few reads of the block, and the quiet period: ~1.5 ms for a small block, ~0.1 s per GB: set-up time.
+constexpr unsigned kSettlePattern = 0xA5C35A3Cu;
+using settle_clock = std::chrono::steady_clock;
+std::mutex g_freed_mu;
+std::vector<std::pair<settle_clock::time_point, size_t>> g_freed;       // what device_free gave back to the driver lately
+
+void note_freed(size_t bytes)
+{
+    std::lock_guard<std::mutex> lk(g_freed_mu);
+    const auto now = settle_clock::now();
+    g_freed.emplace_back(now, bytes);
+    while (!g_freed.empty() && now - g_freed.front().first > std::chrono::seconds(1)) g_freed.erase(g_freed.begin());
+}
+
+size_t freed_lately()
+{
+    std::lock_guard<std::mutex> lk(g_freed_mu);
+    const auto now = settle_clock::now();
+    size_t sum = 0;
+    for (const auto &f : g_freed)
+        if (now - f.first <= std::chrono::seconds(1)) sum += f.second;
+    return sum;
+}
+
+void settle_block(void *ptr, const DeviceBlock &b)
+{
+    unsigned long long *count = nullptr;
+    check(hipHostMalloc(reinterpret_cast<void **>(&count), sizeof *count, hipHostMallocDefault), "hipHostMalloc(settle)");
+    struct Free { void *p; ~Free() { (void)hipHostFree(p); } } guard{count};
+    const double quiet_ms = std::min(2000.0, std::max(1.0, (double)(b.bytes + freed_lately()) / 10e6));
+    const auto nap = std::chrono::microseconds((long)std::min(5000.0, std::max(200.0, 1e3 * quiet_ms / 20)));
+    const auto deadline = settle_clock::now() + std::chrono::milliseconds(3000 + (long)(4 * quiet_ms));
+    for (;;) {
+        check(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ptr), (int)kSettlePattern, b.bytes / 4, nullptr), "hipMemsetD32Async(settle)");
+        check(hipDeviceSynchronize(), "hipDeviceSynchronize(settle)");
+        const auto filled = settle_clock::now();
+        bool held = true;
+        for (;;) {
+            *count = 0;
+            check(launch_count_not(ptr, b.bytes, kSettlePattern, count, nullptr), "launch count");
+            check(hipDeviceSynchronize(), "hipDeviceSynchronize(settle)");
+            if (*count != 0) { held = false; break; }
+            if (std::chrono::duration<double, std::milli>(settle_clock::now() - filled).count() >= quiet_ms) break;
+            std::this_thread::sleep_for(nap);
+        }
+        if (held) return;
+        if (settle_clock::now() > deadline) throw hip_failure("device_alloc: a fresh block kept losing what was written to it (the driver's wipe did not settle)");
+    }
+}
+
 }  // namespace
 
 void *device_alloc(int device, size_t bytes)
@@ -129,6 +195,7 @@ void *device_alloc(int device, size_t bytes)
     prop.type = hipMemAllocationTypePinned;
     prop.location.type = hipMemLocationTypeDevice;
     prop.location.id = device;
+    const bool settle = knobs().place_settle != 0;    // always, but for the measurement build's A/B (settle_block above)
     size_t gran = 0;
     bool vmm = hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) == hipSuccess && gran > 0 &&
                kPlacedChunk % gran == 0;
@@ -152,12 +219,16 @@ void *device_alloc(int device, size_t bytes)
         acc.location = prop.location;
         acc.flags = hipMemAccessFlagsProtReadWrite;
         if (ok) ok = hipMemSetAccess(ptr, blk.bytes, &acc, 1) == hipSuccess;
+        std::string why = "the virtual-memory allocation of " + std::to_string(bytes) + " bytes failed";
+        if (ok && settle) {
+            try { settle_block(ptr, blk); } catch (const std::exception &e) { ok = false; why = e.what(); }
+        }
         if (!ok) {             // out of memory or an unsupported step: undo, report
             if (mapped) (void)hipMemUnmap(ptr, mapped);
             for (hipMemGenericAllocationHandle_t h : blk.handles) (void)hipMemRelease(h);
             (void)hipMemAddressFree(ptr, blk.bytes);
             clear_errors();
-            throw hip_failure("device_alloc: the virtual-memory allocation of " + std::to_string(bytes) + " bytes failed");
+            throw hip_failure("device_alloc: " + why);
         }
     } else {
         clear_errors();

@@ -1,5 +1,7 @@
 import os, sys
 sys.path.insert(0, "/root/repo")
+import os as _os
+_os.environ.setdefault("TOLFG_LIBRARY", _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "tol_amd", "lib", "libtolfg_measure.so"))   # the TOLFG_* switches exist in the measurement build only (tol_amd/csrc/knobs.h)
 import torch, tol_amd
 import bench as BN
 B, ts = 8192, 200

@@ -1,13 +1,15 @@
 #!/bin/bash
-# one gpurun call: GPU suite (default, the callback through the one-workgroup kernel, the two-launch form), smoke, bench.py as the
-# driver starts it and at its own defaults, bench.py --gpus 2 as a plain command (two ranks on this box's one GPU, gloo), rocprofv3
-# stats + PMC passes, shape sweep.  Raw output under gpurun_out/<tag>/; tools/parse_rocprof.py and the profiles/ notes are made from it.
-TAG=${1:-r04}
+# one gpurun call: GPU suite against the shipped library, then against the measurement build (tol_amd/csrc/knobs.h; default plan, the
+# callback through the one-workgroup kernel, the two-launch form), smoke, bench.py as the driver starts it and at its own defaults,
+# bench.py --gpus 2 as a plain command (two ranks on this box's one GPU, gloo), rocprofv3 stats + PMC passes, shape sweep.  Raw output under gpurun_out/<tag>/; tools/parse_rocprof.py and the profiles/ notes are made from it.
+TAG=${1:-r05}
+M=$PWD/tol_amd/lib/libtolfg_measure.so
 O=gpurun_out/$TAG
 mkdir -p $O
 timeout -k 10 900 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; echo "pytest exit $?"; tail -3 $O/pytest_gpu.log
-TOLFG_FORCE_SINGLE_LAUNCH=1 timeout -k 10 600 python -m pytest tests -m gpu -x -q --deselect tests/test_bench_spawn.py > $O/pytest_gpu_single_callback.log 2>&1; echo "pytest (callback through the one-workgroup kernel) exit $?"; tail -2 $O/pytest_gpu_single_callback.log
-TOLFG_FUSED=0 timeout -k 10 600 python -m pytest tests -m gpu -x -q --deselect tests/test_bench_spawn.py > $O/pytest_gpu_two_launch.log 2>&1; echo "pytest (two-launch form) exit $?"; tail -2 $O/pytest_gpu_two_launch.log
+TOLFG_LIBRARY=$M timeout -k 10 900 python -m pytest tests -m gpu -x -q --deselect tests/test_bench_spawn.py > $O/pytest_gpu_measure.log 2>&1; echo "pytest (measurement build) exit $?"; tail -2 $O/pytest_gpu_measure.log
+TOLFG_LIBRARY=$M TOLFG_FORCE_SINGLE_LAUNCH=1 timeout -k 10 600 python -m pytest tests -m gpu -x -q --deselect tests/test_bench_spawn.py > $O/pytest_gpu_single_callback.log 2>&1; echo "pytest (callback through the one-workgroup kernel) exit $?"; tail -2 $O/pytest_gpu_single_callback.log
+TOLFG_LIBRARY=$M TOLFG_FUSED=0 timeout -k 10 600 python -m pytest tests -m gpu -x -q --deselect tests/test_bench_spawn.py > $O/pytest_gpu_two_launch.log 2>&1; echo "pytest (two-launch form) exit $?"; tail -2 $O/pytest_gpu_two_launch.log
 timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke exit $?"; tail -1 $O/smoke.log
 timeout -k 10 500 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_cmd.json 2> $O/bench_driver_cmd.err; echo "bench (the driver's command) exit $?"; python tools/show_bench.py $O/bench_driver_cmd.json
 timeout -k 10 500 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench exit $?"; python tools/show_bench.py $O/bench.json

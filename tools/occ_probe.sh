@@ -1,5 +1,6 @@
 #!/bin/bash
-# occupancy sweep of fg_kernel (stamped probe build; shares, not benchmark numbers)
+# occupancy sweep of fg_kernel (stamped probe build; shares, not benchmark numbers); TOLFG_WAVES_PER_CU: measurement build only
+export TOLFG_LIBRARY=${TOLFG_LIBRARY:-$PWD/tol_amd/lib/libtolfg_measure.so}
 for r in 1 2; do
   for w in 0 8 7 6 5 4; do timeout -k 5 60 ./tools/bin/fgprobe 4096 200 30 1 $w | head -1; done
 done

@@ -24,7 +24,20 @@ def rows(path):
         return list(csv.DictReader(fh))
 
 
+def counter_averages(path):
+    """`parse_rocprof.py --avg <counter_collection.csv>`: every counter averaged over the fg_kernel dispatches (tools/pmc_pass.sh)."""
+    import collections
+    acc = collections.defaultdict(list)
+    for r in rows(path):
+        if "fg_kernel" in r["Kernel_Name"]:
+            acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for k, v in sorted(acc.items()):
+        print("%-32s avg %18.1f  n=%d" % (k, sum(v) / len(v), len(v)))
+
+
 def main():
+    if len(sys.argv) > 2 and sys.argv[1] == "--avg":
+        return counter_averages(sys.argv[2])
     tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
     batch = int(sys.argv[2]) if len(sys.argv) > 2 else 8192
     ts = int(sys.argv[3]) if len(sys.argv) > 3 else 200

@@ -11,6 +11,8 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+import os as _os
+_os.environ.setdefault("TOLFG_LIBRARY", _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "tol_amd", "lib", "libtolfg_measure.so"))   # the TOLFG_* switches exist in the measurement build only (tol_amd/csrc/knobs.h)
 import tol_amd
 import bench as BN
 

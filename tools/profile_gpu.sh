@@ -4,7 +4,8 @@
 # Counters are collected in their own passes (kernel-trace only, no other trace domains).
 set -e
 TAG=${1:-r01}
-ARGS=${2:-"--steps 50 --warmup 5 --no-cpu-baseline --no-configs --no-calibration"}
+# (--no-native-multi: under the profiler bench.py must not start its native-leg child -- the profiler's preloaded library would ride into it)
+ARGS=${2:-"--steps 50 --warmup 5 --no-cpu-baseline --no-configs --no-calibration --no-native-multi"}
 OUT=$PWD/gpurun_out/prof_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
 export TMPDIR=/tmp
