@@ -638,7 +638,7 @@ class _Raw:
         self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (ptr, False), "version": 2}
 
 
-def native_workload(tol_amd, torch, devices, mission, aircraft, ts, dtype, total, steps, warmup, x_buffers, issue, scaling, what):
+def native_workload(tol_amd, torch, devices, mission, aircraft, ts, dtype, total, steps, warmup, x_buffers, issue, scaling, what, gather="rccl"):
     """One workload through the native several-GPUs-one-process host path (tol_amd/csrc/multi.cpp: one launch stream, one gather
     stream and one issuing thread per device, grouped ncclAllGather of the objectives over four rotating buffers), the step loop
     itself issued from native code (tolfg_multi_time_steps).  Inputs as bench.py's torch.distributed path makes them: initial
@@ -646,6 +646,7 @@ def native_workload(tol_amd, torch, devices, mission, aircraft, ts, dtype, total
     nd = len(devices)
     m = tol_amd.Multi(mission, aircraft, ts=ts, dtype=dtype, devices=devices)
     m.set_issue(issue)
+    m.set_gather(gather)
     t0 = time.perf_counter()
     m.set_trajectories(make_trajectories(tol_amd, total, 0, mission, len(aircraft)))
     setup_s = time.perf_counter() - t0
@@ -682,6 +683,17 @@ def native_workload(tol_amd, torch, devices, mission, aircraft, ts, dtype, total
     obj = m.gather_wait(m.step(dX=sets[0]))
     assert np.isfinite(obj).all() and obj.shape == (total,), "non-finite objective"
     m.sync()
+    # the same object and buffers, the objectives stored straight into one pinned host vector by the finalizing waves instead of
+    # all-gathered (tolfg_multi_set_gather HOST): what a host-side consumer of the objectives pays per step
+    other = None
+    if gather == "rccl":
+        m.set_gather("host")
+        h = m.time_steps(steps, warm=max(5, min(warm, 2000)), x_sets=sets)
+        obj2 = m.gather_wait(m.step(dX=sets[0]))
+        assert np.array_equal(obj2, obj), "the host-gathered objectives differ from the all-gathered ones"
+        other = {"gather": "host", "ms_per_step": 1e-3 * h["wall_us_per_step"], "eval_us": h["launch_us_per_step"], "gather_us": h["gather_us"],
+                 "issue_us_per_step": h["issue_us_per_step"], "node_evals_per_s": total * ts / (h["wall_us_per_step"] * 1e-6)}
+        m.set_gather("rccl")
     wall = t["wall_us_per_step"] * 1e-6
     per_dev = t["launch_us_per_device"]
     # algorithmic bytes of the widest shard through a host-side batch object of the same description (no GPU work)
@@ -690,7 +702,8 @@ def native_workload(tol_amd, torch, devices, mission, aircraft, ts, dtype, total
     alg0 = bt.algorithmic_bytes(shards[0][1] - shards[0][0])
     bt.close()
     rec = {"workload": what, "scaling": scaling, "n_gpus": nd, "batch": total, "batch_per_gpu": shards[0][1] - shards[0][0], "ts": ts, "dtype": dtype,
-           "steps": steps, "warmup_steps_run": warm + 2 + 5, "x_buffers": len(sets), "issue": t["issue"],
+           "steps": steps, "warmup_steps_run": warm + 2 + 5, "x_buffers": len(sets), "issue": t["issue"], "gather": t["gather"],
+           "objectives_stored_to_host_instead": other,
            "ms_per_step": 1e3 * wall, "node_evals_per_s": total * ts / wall,
            "eval_us": t["launch_us_per_step"], "eval_us_per_device": per_dev, "gather_us": t["gather_us"],
            "issue_us_per_step": t["issue_us_per_step"],

@@ -378,6 +378,15 @@ int  tolfg_multi_step(tolfg_multi *m, const void *const *dX, int n_devices, int 
  * one-thread-per-device form); a tolfg_multi_step then needs no rendezvous of the host threads.  Same results. */
 enum { TOLFG_MULTI_ISSUE_GROUPED = 0, TOLFG_MULTI_ISSUE_THREADS = 1 };
 int  tolfg_multi_set_issue(tolfg_multi *m, int mode);
+/* Where the objectives are gathered.  RCCL (default): ncclAllGather into a device vector on every device.  HOST: no collective
+ * at all -- every device's finalizing waves store their trajectories' objectives straight into ONE pinned, device-mapped host
+ * vector, each shard at its global offset, so that a gather is an event behind the launch (gather_begin) and a wait for it
+ * (gather_wait): for consumers on the host (Monte-Carlo statistics, one SQP driver per trajectory) that takes the collective's
+ * launch and its stream hand-over out of every step (one device: 20.4 -> 14 us per step at 128 trajectories,
+ * profiles/r05_native_multi.md); the devices do not receive each other's objectives.  Results are the same numbers.
+ * Call while nothing is in flight (it waits). */
+enum { TOLFG_MULTI_GATHER_RCCL = 0, TOLFG_MULTI_GATHER_HOST = 1 };
+int  tolfg_multi_set_gather(tolfg_multi *m, int mode);
 /* Candidates of the per-device placement search for the G buffers (tolfg_batch_alloc_outputs) that the NEXT
  * tolfg_multi_set_trajectories runs, the devices searching side by side on their own threads: default 12 (each device holds
  * its candidates within half of its free memory, ~0.05 s per candidate); 0 or 1 = one allocation, no search. */
@@ -391,7 +400,7 @@ typedef struct tolfg_multi_timing {
     double launch_us_per_step;   /* the slowest device's launch_us_per_device                                         */
     double issue_us_per_step;    /* host time spent issuing, / steps                                                  */
     double gather_us;            /* one synchronous gather (begin + wait), nothing else in flight; 0 without gather   */
-    int    devices, steps, issue;
+    int    devices, steps, issue, gather;
 } tolfg_multi_timing;
 int  tolfg_multi_time_steps(tolfg_multi *m, int n_x, const void *const *dX, int needF, int needG, int gather, int warm, int steps,
                             tolfg_multi_timing *out, double *launch_us_per_device);

@@ -25,7 +25,7 @@ class _Raw:
         self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (ptr, False), "version": 2}
 
 
-def pipeline(out, mission, dtype, total, parts, N, issue):
+def pipeline(out, mission, dtype, total, parts, N, issue, gather="rccl"):
     """The asynchronous gather (tolfg_multi_step / gather_begin / gather_wait) against the synchronous one: `nsteps` steps on
     different inputs, the host waiting for gather j-1 only after it has issued step j, then the same inputs one by one through
     eval_from + gather_objectives.  Also: a ticket that has expired, the native step loop, the state after it."""
@@ -36,6 +36,7 @@ def pipeline(out, mission, dtype, total, parts, N, issue):
     trajs = trajectories(tolfg, mission, total)
     m = tolfg.Multi(mission, air, ts=N, dtype=dtype, devices=[0] * parts)
     m.set_issue(issue)
+    m.set_gather(gather)
     m.set_placement(2)
     m.set_trajectories(trajs)
     m.x0()
@@ -86,6 +87,10 @@ def pipeline(out, mission, dtype, total, parts, N, issue):
     res["timing"] = np.array(json.dumps(tim))
     m.eval_from(sets[1])
     res["obj_after_loop"] = m.gather_objectives()
+    # the other way of gathering on the same object: the same numbers
+    m.set_gather("host" if gather == "rccl" else "rccl")
+    res["obj_other_gather"] = m.gather_wait(m.step(dX=sets[2]))
+    res["mean_other_gather"] = np.array(m.mean_objective())
     m.close()
     # the single batch on set 0 (= the initial guesses)
     bt = tolfg.Batch(mission, air, ts=N, dtype=dtype)
@@ -102,7 +107,7 @@ def pipeline(out, mission, dtype, total, parts, N, issue):
 def main():
     out, mission, dtype, total, parts, N, wind = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6]), sys.argv[7]
     if wind.startswith("pipeline:"):
-        return pipeline(out, mission, dtype, total, parts, N, wind.split(":")[1])
+        return pipeline(out, mission, dtype, total, parts, N, *wind.split(":")[1:])
     import torch
     import tol_amd as tolfg
     from helpers import random_wind_table

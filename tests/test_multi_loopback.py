@@ -112,16 +112,17 @@ def test_several_parts_on_one_device(tolfg, oracle, tmp_path, mission, dtype, to
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("issue", ["grouped", "threads"])
+@pytest.mark.parametrize("issue,gather", [("grouped", "rccl"), ("threads", "rccl"), ("grouped", "host"), ("threads", "host")])
 @pytest.mark.parametrize("mission,dtype,total,parts,N", [("mixed", "f64", 23, 4, 200), ("S10", "f32", 9, 4, 52)])
-def test_asynchronous_gather_equals_the_synchronous_one(tolfg, tmp_path, mission, dtype, total, parts, N, issue):
+def test_asynchronous_gather_equals_the_synchronous_one(tolfg, tmp_path, mission, dtype, total, parts, N, issue, gather):
     """tolfg_multi_step / gather_begin / gather_wait on 4 loop-back parts -- 11 steps on different inputs over
     4 rotating objective buffers, the host waiting for gather j-1 with evaluation j already issued -- deliver bitwise what
     eval_from + the synchronous gather_objectives deliver, in both ways of issuing the collective (one group call; one call
-    per device thread).  A ticket expires after 4 further gathers; the native step loop (tolfg_multi_time_steps) leaves the
-    object in working order."""
+    per device thread) and both ways of gathering (ncclAllGather into device vectors; item 7: the finalizing waves storing
+    straight into one pinned host vector, no collective).  A ticket expires after 4 further gathers; the native step loop
+    (tolfg_multi_time_steps) leaves the object in working order; switching the way of gathering changes no number."""
     import json
-    r = run_worker(tmp_path, mission, dtype, total, parts, N, "pipeline:" + issue)
+    r = run_worker(tmp_path, mission, dtype, total, parts, N, f"pipeline:{issue}:{gather}")
     assert "loopback_nccl" in str(r["library"])
     a, s = r["obj_async"], r["obj_sync"]
     assert a.shape == s.shape == (11, total) and np.isfinite(a).all()
@@ -131,11 +132,14 @@ def test_asynchronous_gather_equals_the_synchronous_one(tolfg, tmp_path, mission
     assert np.array_equal(a[0], r["obj_single"])                           # set 0 = the initial guesses: the single batch's objectives
     assert str(r["expired"]).startswith(str(tolfg.capi.ERR_ARG)) and "ticket" in str(r["expired"])
     assert np.array_equal(r["obj_run_last"], s[int(r["run_last_set"])])
-    assert float(r["mean_last"]) == pytest.approx(float(s[-1].astype(np.float64).mean()), rel=1e-12 if dtype == "f64" else 1e-6)
+    tol = 1e-12 if dtype == "f64" else 1e-6
+    assert float(r["mean_last"]) == pytest.approx(float(s[-1].astype(np.float64).mean()), rel=tol)
     assert np.array_equal(r["obj_after_loop"], s[1])
+    assert np.array_equal(r["obj_other_gather"], s[2])
+    assert float(r["mean_other_gather"]) == pytest.approx(float(s[2].astype(np.float64).mean()), rel=tol)
     tim = json.loads(str(r["timing"]))
-    for t, gather in zip(tim, (True, False, True)):
-        assert t["issue"] == issue and t["devices"] == parts
+    for t, with_gather in zip(tim, (True, False, True)):
+        assert t["issue"] == issue and t["gather"] == gather and t["devices"] == parts
         assert t["wall_us_per_step"] > 0 and t["launch_us_per_step"] > 0 and len(t["launch_us_per_device"]) == parts
-        assert (t["gather_us"] > 0) == gather
+        assert (t["gather_us"] > 0) == with_gather
         assert t["wall_us_per_step"] >= 0.5 * t["launch_us_per_step"]

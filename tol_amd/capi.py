@@ -58,11 +58,12 @@ class BatchConfig(C.Structure):
 
 class MultiTiming(C.Structure):
     _fields_ = [("wall_us_per_step", C.c_double), ("launch_us_per_step", C.c_double), ("issue_us_per_step", C.c_double),
-                ("gather_us", C.c_double), ("devices", C.c_int), ("steps", C.c_int), ("issue", C.c_int)]
+                ("gather_us", C.c_double), ("devices", C.c_int), ("steps", C.c_int), ("issue", C.c_int), ("gather", C.c_int)]
 
 
 MULTI_SLOTS = 4
 ISSUE_GROUPED, ISSUE_THREADS = 0, 1
+GATHER_RCCL, GATHER_HOST = 0, 1
 _vpp = C.POINTER(C.c_void_p)
 
 # snFunA, include/snopt/snopt.h:60-66 of the reference
@@ -138,6 +139,7 @@ SYMBOLS = {
     "tolfg_multi_gather_wait": (C.c_int, [C.c_void_p, C.c_ulong, C.c_void_p]),
     "tolfg_multi_step": (C.c_int, [C.c_void_p, _vpp, C.c_int, C.c_int, C.POINTER(C.c_ulong)]),
     "tolfg_multi_set_issue": (C.c_int, [C.c_void_p, C.c_int]),
+    "tolfg_multi_set_gather": (C.c_int, [C.c_void_p, C.c_int]),
     "tolfg_multi_set_placement": (C.c_int, [C.c_void_p, C.c_int]),
     "tolfg_multi_time_steps": (C.c_int, [C.c_void_p, C.c_int, _vpp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                          C.POINTER(MultiTiming), _dp]),

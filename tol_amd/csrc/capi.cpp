@@ -578,6 +578,12 @@ int tolfg_multi_set_issue(tolfg_multi *h, int mode)
     return guarded([&] { h->m->set_issue(mode); });
 }
 
+int tolfg_multi_set_gather(tolfg_multi *h, int mode)
+{
+    if (!h) return fail(TOLFG_ERR_ARG, "null handle");
+    return guarded([&] { h->m->set_gather(mode); });
+}
+
 int tolfg_multi_eval_from(tolfg_multi *h, const void *const *dX, int n_devices, int needF, int needG)
 {
     if (!h || !dX || n_devices != h->m->devices()) return fail(TOLFG_ERR_ARG, "tolfg_multi_eval_from: one X pointer per device is required");
@@ -615,6 +621,7 @@ int tolfg_multi_time_steps(tolfg_multi *h, int n_x, const void *const *dX, int n
         out->devices = h->m->devices();
         out->steps = steps;
         out->issue = h->m->issue();
+        out->gather = h->m->gather();
     });
 }
 

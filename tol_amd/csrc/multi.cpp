@@ -167,7 +167,7 @@ multi::multi(const std::string &mission, const std::string &root, const std::vec
             // onto the chip when the first wave slots free up, not when the launch's backlog of tiles is through
             int least = 0, greatest = 0;
             if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { least = greatest = 0; clear_hip_errors(); }
-            check(hipStreamCreateWithPriority(&p.gstream, hipStreamNonBlocking, greatest), "hipStreamCreateWithPriority");
+            check(hipStreamCreateWithPriority(&p.gstream, hipStreamNonBlocking, knobs().multi_gather_priority ? greatest : least), "hipStreamCreateWithPriority");
             for (int k = 0; k < kSlots; ++k) {
                 check(hipEventCreateWithFlags(&p.ev_launch[k], hipEventDisableTiming), "hipEventCreate");
                 check(hipEventCreateWithFlags(&p.ev_gather[k], hipEventDisableTiming), "hipEventCreate");
@@ -233,7 +233,8 @@ void multi::free_buffers()
     DeviceGuard guard;
     for (int k = 0; k < kSlots; ++k) {
         if (hAll_[k]) (void)hipHostFree(hAll_[k]);
-        hAll_[k] = nullptr;
+        if (hObj_[k]) (void)hipHostFree(hObj_[k]);
+        hAll_[k] = hObj_[k] = nullptr;
     }
     for (Part &p : part_) {
         (void)hipSetDevice(p.device);
@@ -309,6 +310,11 @@ void multi::on_every_device(const std::function<void(Part &)> &fn)
     }
 }
 
+const void *multi::gathered(int i) const
+{
+    return gather_ == GATHER_HOST ? hObj_[last_gather_slot_] : part_.at(i).dAll[last_gather_slot_];
+}
+
 int multi::nccl_type() const { return dtype_ == TOLFG_F64 ? kNcclFloat64 : kNcclFloat32; }
 
 int multi::rccl_version() const
@@ -322,6 +328,13 @@ void multi::set_issue(int mode)
 {
     if (mode != ISSUE_GROUPED && mode != ISSUE_THREADS) throw std::invalid_argument("tolfg_multi_set_issue: unknown mode");
     issue_ = mode;
+}
+
+void multi::set_gather(int mode)
+{
+    if (mode != GATHER_RCCL && mode != GATHER_HOST) throw std::invalid_argument("tolfg_multi_set_gather: unknown mode");
+    sync();
+    gather_ = mode;
 }
 
 void multi::set_trajectories(long total, const tolfg_traj *trajs, int place_tries)
@@ -342,8 +355,13 @@ void multi::set_trajectories(long total, const tolfg_traj *trajs, int place_trie
     {
         DeviceGuard guard;
         check(hipSetDevice(part_[0].device), "hipSetDevice");
-        for (int k = 0; k < kSlots; ++k)
+        for (int k = 0; k < kSlots; ++k) {
             check(hipHostMalloc(&hAll_[k], elem() * (size_t)width_ * world, hipHostMallocDefault), "hipHostMalloc(gathered)");
+            // portable + mapped: one host vector every device can store into (GATHER_HOST); a pinned host pointer is its own
+            // device address under unified addressing, on every device
+            check(hipHostMalloc(&hObj_[k], elem() * (size_t)total, hipHostMallocPortable | hipHostMallocMapped), "hipHostMalloc(host objectives)");
+            std::memset(hObj_[k], 0, elem() * (size_t)total);
+        }
     }
     on_every_device([&](Part &p) {
         check(hipSetDevice(p.device), "hipSetDevice");
@@ -427,7 +445,8 @@ void multi::set_wind_tables(const double *wind_enu)
 void multi::part_eval(Part &p, int slot, bool needF, bool needG, const void *X)
 {
     if (p.hi <= p.lo) return;
-    if (needF) {
+    if (needF && gather_ == GATHER_RCCL) {
+        // (GATHER_HOST: the event of kSlots steps back sits on this very stream, ahead of this launch)
         // slot reuse: the gather that last read this objective buffer (kSlots gathers back) must be through.  It normally is,
         // long ago -- then nothing is put into the launch stream (a wait marker between two launches costs the second a few us)
         const hipError_t q = hipEventQuery(p.ev_gather[slot]);
@@ -438,12 +457,19 @@ void multi::part_eval(Part &p, int slot, bool needF, bool needG, const void *X)
             check(q, "hipEventQuery");
         }
     }
+    // where the finalizing waves put the objectives: the device buffer the all-gather sends, or (GATHER_HOST) this shard's
+    // place in the pinned host vector
+    void *obj = gather_ == GATHER_HOST ? static_cast<char *>(hObj_[slot]) + elem() * (size_t)p.lo : p.dObj[slot];
     p.b->eval((int)(p.hi - p.lo), X ? X : p.dX, ldx_, p.dF, ldf_, p.dG, ldg_, p.dWind, needF ? 1 : 0, needG ? 1 : 0, p.stream,
-              needF ? p.dObj[slot] : nullptr);
+              needF ? obj : nullptr);
 }
 
 void multi::part_gather_pre(Part &p, int slot)
 {
+    if (gather_ == GATHER_HOST) {      // the whole gather: an event behind the launch whose waves wrote the host vector
+        check(hipEventRecord(p.ev_gather[slot], p.stream), "hipEventRecord(host gather)");
+        return;
+    }
     // the gather stream picks up where the launch stream stands now: behind the evaluation whose objectives it carries
     check(hipEventRecord(p.ev_launch[slot], p.stream), "hipEventRecord(launch)");
     check(hipStreamWaitEvent(p.gstream, p.ev_launch[slot], 0), "hipStreamWaitEvent(gather)");
@@ -451,14 +477,13 @@ void multi::part_gather_pre(Part &p, int slot)
 
 void multi::part_gather_call(Part &p, int slot)
 {
+    if (gather_ == GATHER_HOST) return;
     nccl_check(rccl_api::get().AllGather(p.dObj[slot], p.dAll[slot], (size_t)width_, nccl_type(), p.comm, p.gstream), "ncclAllGather");
 }
 
 void multi::part_gather_post(Part &p, int slot)
 {
-    if (p.index == 0)      // device 0's copy of the gathered vector follows its gather on the same stream, into pinned memory
-        check(hipMemcpyAsync(hAll_[slot], p.dAll[slot], elem() * (size_t)width_ * devices(), hipMemcpyDeviceToHost, p.gstream),
-              "hipMemcpyAsync(gathered)");
+    if (gather_ == GATHER_HOST) return;
     check(hipEventRecord(p.ev_gather[slot], p.gstream), "hipEventRecord(gather)");
 }
 
@@ -481,10 +506,12 @@ unsigned long multi::gather_begin()
         DeviceGuard guard;
         const rccl_api &nc = rccl_api::get();
         for (Part &p : part_) { check(hipSetDevice(p.device), "hipSetDevice"); part_gather_pre(p, slot); }
-        nccl_check(nc.GroupStart(), "ncclGroupStart");
-        for (Part &p : part_) part_gather_call(p, slot);
-        nccl_check(nc.GroupEnd(), "ncclGroupEnd");
-        for (Part &p : part_) { check(hipSetDevice(p.device), "hipSetDevice"); part_gather_post(p, slot); }
+        if (gather_ == GATHER_RCCL) {
+            nccl_check(nc.GroupStart(), "ncclGroupStart");
+            for (Part &p : part_) part_gather_call(p, slot);
+            nccl_check(nc.GroupEnd(), "ncclGroupEnd");
+            for (Part &p : part_) { check(hipSetDevice(p.device), "hipSetDevice"); part_gather_post(p, slot); }
+        }
     }
     last_gather_slot_ = slot;
     evaluated_since_gather_ = false;
@@ -495,10 +522,11 @@ unsigned long multi::step(bool needF, bool needG, const void *const *dX)
 {
     if (total_ < 1) throw std::invalid_argument("tolfg_multi: set_trajectories first");
     if (!needF) throw std::invalid_argument("tolfg_multi_step: the gather carries the objectives, so F is needed");
-    if (issue_ != ISSUE_THREADS) {
+    if (issue_ != ISSUE_THREADS && gather_ == GATHER_RCCL) {
         eval(needF, needG, dX);
         return gather_begin();
     }
+    // one wake-up of the issuing threads per step: every thread issues its launch and its part of the gather
     const int slot = (int)(seq_ % kSlots);
     on_every_device([&](Part &p) {
         part_eval(p, slot, needF, needG, dX ? dX[p.index] : nullptr);
@@ -526,7 +554,19 @@ void multi::gather_wait(unsigned long ticket, void *host_out)
     // the gather is behind the evaluation that fed it: that evaluation's health can be asked now
     for (Part &p : part_)
         if (p.b->take_lost_partial()) throw hip_failure("device " + std::to_string(p.device) + ": an evaluation lost an objective partial");
-    if (host_out) compact_gathered(hAll_[slot], elem(), total_, devices(), host_out);
+    if (host_out && gather_ == GATHER_HOST) {
+        std::memcpy(host_out, hObj_[slot], elem() * (size_t)total_);      // global order already: every shard was stored at its offset
+    } else if (host_out) {
+        // device 0's copy of the gathered vector comes to the host only when somebody asks for it: a step that nobody reads
+        // on the host (the steady state of a Monte-Carlo loop) carries no copy command
+        Part &p0 = part_[0];
+        DeviceGuard guard;
+        check(hipSetDevice(p0.device), "hipSetDevice");
+        check(hipMemcpyAsync(hAll_[slot], p0.dAll[slot], elem() * (size_t)width_ * devices(), hipMemcpyDeviceToHost, p0.gstream),
+              "hipMemcpyAsync(gathered)");
+        check(hipStreamSynchronize(p0.gstream), "hipStreamSynchronize(gathered)");
+        compact_gathered(hAll_[slot], elem(), total_, devices(), host_out);
+    }
 }
 
 void multi::gather_objectives(void *host_out)
@@ -539,6 +579,13 @@ void multi::gather_objectives(void *host_out)
 double multi::mean_objective()
 {
     if (total_ < 1) throw std::invalid_argument("tolfg_multi: set_trajectories first");
+    if (gather_ == GATHER_HOST) {      // the objectives are on the host already: wait for the launches, add them up in global order
+        sync();
+        const int hs = (int)((seq_ > 0 && !evaluated_since_gather_ ? seq_ - 1 : seq_) % kSlots);
+        double sum = 0.0;
+        for (long t = 0; t < total_; ++t) sum += dtype_ == TOLFG_F64 ? static_cast<const double *>(hObj_[hs])[t] : (double)static_cast<const float *>(hObj_[hs])[t];
+        return sum / (double)total_;
+    }
     const rccl_api &nc = rccl_api::get();
     // the objectives of the evaluation issued last: the slot the next gather would carry, or -- right after a gather, nothing
     // evaluated since -- the one it carried; either way the buffer the launch stream wrote last
@@ -573,7 +620,7 @@ void multi::sync()
 void multi::steps_run(int n, int n_x, const void *const *dX, bool needF, bool needG, bool gather, unsigned long first_step)
 {
     const int world = devices();
-    if (gather && issue_ == ISSUE_THREADS) {
+    if (gather && (issue_ == ISSUE_THREADS || gather_ == GATHER_HOST)) {
         // every device's thread issues its own n steps -- launch, event, wait, its communicator's all-gather, copy, event --
         // without meeting the other threads on the host: the collective's kernels meet on the devices
         const unsigned long seq0 = seq_;

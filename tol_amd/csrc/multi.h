@@ -91,8 +91,9 @@ public:
     void gather_objectives(void *host_out);
     // Monte-Carlo mean of the objectives: all-reduce(sum) of each device's partial sum (double)
     double mean_objective();
-    // device pointer (device i) of the gathered, padded vector of the last gather: devices() blocks of shard_width() values
-    const void *gathered(int i) const { return part_.at(i).dAll[last_gather_slot_]; }
+    // device pointer (device i) of the last gather's result: the padded vector, devices() blocks of shard_width() values
+    // (GATHER_HOST: the pinned host vector, `total` values in global order, the same address on every device)
+    const void *gathered(int i) const;
     void sync();
     std::string rccl_path() const { return rccl_api::get().path; }
     int rccl_version() const;
@@ -104,6 +105,16 @@ public:
     enum { ISSUE_GROUPED = 0, ISSUE_THREADS = 1 };
     void set_issue(int mode);
     int issue() const { return issue_; }
+
+    // Where the objectives are gathered.  RCCL (default): ncclAllGather into a device vector on EVERY device (north star: "RCCL over
+    // xGMI only for the final objective gather").  HOST: no collective at all -- every device's finalizing waves store their
+    // trajectories' objectives straight into ONE pinned, device-mapped host vector, each shard at its global offset; a gather is
+    // then nothing but an event behind the launch (gather_begin) and a wait for it (gather_wait).  For consumers on the host
+    // (Monte-Carlo statistics, an SQP driver per trajectory) that takes the collective's launch, its stream hand-over and its
+    // 10 us out of every step; the devices do not get each other's objectives.  Switch while nothing is in flight.
+    enum { GATHER_RCCL = 0, GATHER_HOST = 1 };
+    void set_gather(int mode);
+    int gather() const { return gather_; }
 
     // Measurement aid (bench.py --native-multi): `warm` untimed steps, then `steps` steps -- launch + asynchronous gather,
     // inputs rotating over n_x sets of caller-supplied X buffers ([n_x][devices()] device pointers; n_x = 0: the library's
@@ -129,11 +140,13 @@ private:
     std::vector<Part> part_;
     int dtype_;
     int issue_ = ISSUE_GROUPED;
+    int gather_ = GATHER_RCCL;
     long total_ = 0, width_ = 0, ldx_ = 0, ldf_ = 0, ldg_ = 0;
     unsigned long seq_ = 0;             // gathers begun so far; the next evaluation's objectives go to slot seq_ % kSlots
     int last_gather_slot_ = 0;
     bool evaluated_since_gather_ = false;
     void *hAll_[kSlots] = {};           // pinned host copies of the gathered, padded objectives
+    void *hObj_[kSlots] = {};           // GATHER_HOST: pinned, mapped host vectors [total] the finalizing waves write (global order)
     size_t elem() const { return dtype_ == TOLFG_F64 ? 8 : 4; }
     int nccl_type() const;
     void free_buffers();

@@ -175,7 +175,11 @@ void settle_block(void *ptr, const DeviceBlock &b)
             if (std::chrono::duration<double, std::milli>(settle_clock::now() - filled).count() >= quiet_ms) break;
             std::this_thread::sleep_for(nap);
         }
-        if (held) return;
+        if (held) {       // handed out zeroed, as the driver's own clear leaves a fresh block
+            check(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ptr), 0, b.bytes / 4, nullptr), "hipMemsetD32Async(settle)");
+            check(hipDeviceSynchronize(), "hipDeviceSynchronize(settle)");
+            return;
+        }
         if (settle_clock::now() > deadline) throw hip_failure("device_alloc: a fresh block kept losing what was written to it (the driver's wipe did not settle)");
     }
 }

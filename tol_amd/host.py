@@ -613,6 +613,11 @@ class Multi:
         its own communicator)."""
         self._rc(self._L.tolfg_multi_set_issue(self._h, {"grouped": capi.ISSUE_GROUPED, "threads": capi.ISSUE_THREADS}[mode]))
 
+    def set_gather(self, mode):
+        """'rccl' (ncclAllGather into a device vector on every device) | 'host' (the finalizing waves store the objectives straight
+        into one pinned host vector: no collective in the step)."""
+        self._rc(self._L.tolfg_multi_set_gather(self._h, {"rccl": capi.GATHER_RCCL, "host": capi.GATHER_HOST}[mode]))
+
     def set_placement(self, tries):
         self._rc(self._L.tolfg_multi_set_placement(self._h, int(tries)))
 
@@ -639,6 +644,7 @@ class Multi:
         self._rc(self._L.tolfg_multi_time_steps(self._h, n_x, arr, int(needF), int(needG), int(gather), int(warm), int(steps), C.byref(t), per))
         return {"wall_us_per_step": t.wall_us_per_step, "launch_us_per_step": t.launch_us_per_step, "issue_us_per_step": t.issue_us_per_step,
                 "gather_us": t.gather_us, "devices": t.devices, "steps": t.steps, "issue": ("grouped", "threads")[t.issue],
+                "gather": ("rccl", "host")[t.gather],
                 "launch_us_per_device": [per[i] for i in range(nd)]}
 
     def rccl_version(self):
