@@ -1092,12 +1092,14 @@ def main():
             torch.cuda.synchronize()
             torch.cuda.empty_cache()
             left = wait_for_pids([c["pid"] for c in cards], 30.0) if world > 1 else []
-            n_native = world if args.backend == "nccl" else min(world, max(ndev, 1))      # a gloo rehearsal shares GPUs: the native leg takes the devices there are
+            # the native leg takes the devices this process can see: all `world` of them under RCCL (one rank per GPU), fewer when a
+            # gloo rehearsal shared GPUs or the launcher masked the devices per rank
+            n_native = min(world, max(ndev, 1))
             nm = run_native_child(n_native, args, "grouped")
             if left:
                 nm["ranks_still_alive_at_start"] = left
             if n_native != world:
-                nm["note_devices"] = f"{world} ranks shared {ndev} device(s) (gloo rehearsal): the native leg ran over {n_native}"
+                nm["note_devices"] = f"{world} ranks, {ndev} device(s) visible to rank 0: the native leg ran over {n_native}"
             line["native_multi"] = nm
             if n_native > 1 and "error" not in nm:
                 # the other way of issuing the collective (one call per device thread), headline only, in a process of its own

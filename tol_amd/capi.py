@@ -227,7 +227,11 @@ def lib():
     """The product library (tol_amd/lib/libtolfg.so, or the build TOLFG_LIBRARY names)."""
     global _lib
     if _lib is None:
-        _lib = _load(lib_path())
+        path = lib_path()
+        if os.environ.get("TOLFG_LIBRARY"):      # a redirection of the whole library is worth one line
+            import sys
+            sys.stderr.write(f"tol_amd: TOLFG_LIBRARY is set: loading {path} instead of the shipped library\n")
+        _lib = _load(path)
     return _lib
 
 

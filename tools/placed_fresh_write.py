@@ -35,7 +35,34 @@ def raw_hipmalloc(count):
     return torch.as_tensor(_Owned(p.value, count), device="cuda")
 
 
+def never_free():
+    """`placed_fresh_write.py never-free`: round 4's allocator (TOLFG_PLACE_SETTLE=0), blocks allocated and filled one after the other with
+    none freed in between -- does the zeroing follow frees, or every allocation?  (profiles/r05/never_free.txt: it follows frees.)"""
+    M = tol_amd.measure_lib()
+    os.environ["TOLFG_PLACE_SETTLE"] = "0"
+    tol_amd.Batch("S10", ["tempest"], ts=4, library=M).close()
+    torch.zeros(1, device="cuda")
+    for count in (1 << 20, 32 << 20):
+        keep, lost_now, lost_later = [], 0, 0
+        for i in range(60 if count == 1 << 20 else 20):
+            t = tol_amd.device_alloc((count,), "f64", library=M)
+            t.fill_(1.0)
+            torch.cuda.synchronize()
+            lost_now += int((t != 1.0).sum()) > 0
+            keep.append(t)
+        time.sleep(0.05)
+        for t in keep:
+            lost_later += int((t != 1.0).sum()) > 0
+        print(f"never freeing, {count} doubles: {lost_now} of {len(keep)} blocks had lost writes right after the fill, {lost_later} when looked at "
+              f"50 ms after the last allocation", flush=True)
+        del keep, t
+        torch.cuda.synchronize()
+        time.sleep(0.5)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "never-free":
+        return never_free()
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
     forms = sys.argv[2].split(",") if len(sys.argv) > 2 else ["0", "1", "torch", "hipMalloc"]
     M = tol_amd.measure_lib()

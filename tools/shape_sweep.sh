@@ -1,6 +1,6 @@
 #!/bin/bash
 # throughput across problem shapes (not the headline; for the record)
-run() { timeout -k 10 200 python bench.py --steps 60 --warmup 5 --no-cpu-baseline --no-configs "$@" 2>/dev/null | tail -1 | python3 -c "
+run() { timeout -k 10 200 python bench.py --steps 60 --warmup 5 --no-cpu-baseline --no-configs --no-native-multi "$@" 2>/dev/null | tail -1 | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read()); c=d['config']; r=d['roofline']
 print('| %s | %s | %d | %d | %s | %s | %.3g | %.0f | %.1f |' % (c['mission'], c['aircraft'], c['ts'], c['batch_per_gpu'], d['dtype'], c['pattern'], d['value'], r['achieved'], 100*r['frac']))"; }

@@ -42,3 +42,20 @@ if "headline_same_x_every_step" in d:
     c = d["headline_same_x_every_step"]
     print("  side: the headline with the same X buffer every step (x from the Infinity Cache): %.1f us per launch = %.3f of peak over the same algorithmic bytes"
           % (1e3 * c["kernel_ms"], c["frac_of_hbm_peak"]))
+for key in ("native_multi", "native_multi_threads"):
+    if key in d:
+        c = d[key]
+        if "error" in c:
+            print("  %s: NO RECORD: %s" % (key, c["error"]))
+            continue
+        h = c.get("objectives_stored_to_host_instead") or {}
+        print("  %s (C++ tolfg_multi, %d device(s), issue %s, rccl %s): step %.1f us (%.4g node-evals/s), per launch %.1f us, without the gather %.1f us; one synchronous gather %.1f us; "
+              "host issue %.1f us per step; objectives stored to host instead of gathered: step %.1f us"
+              % (key, c["n_gpus"], c.get("issue"), (c.get("rccl") or {}).get("version_code"), 1e3 * c["ms_per_step"], c["node_evals_per_s"], c["eval_us"],
+                 c["eval_us_without_gather"], c["gather_us"], c["issue_us_per_step"], 1e3 * h.get("ms_per_step", nan)))
+        for r in c.get("configs", []):
+            hh = r.get("objectives_stored_to_host_instead") or {}
+            print("    config %d B=%d %s: step %.1f us, per launch %.1f us (without the gather %.1f), stored to host instead: %.1f us"
+                  % (r["config"], r["batch"], r["dtype"], 1e3 * r["ms_per_step"], r["eval_us"], r["eval_us_without_gather"], 1e3 * hh.get("ms_per_step", nan)))
+if "ranks" in d:
+    print("  ranks seen: %d; %s" % (d.get("world_seen", 0), "; ".join("rank %d dev %s %s shard %s" % (c["rank"], c["device"], c["pci_bus_id"], c["shard"]) for c in d["ranks"])))
