@@ -429,10 +429,14 @@ def sharded_run(tol_amd, job, mission, aircraft, ts, dtype, pattern, per_gpu, gl
     def step(i):
         s = i % NOBJ
         if coll and pending[s] is not None:
-            # buffer reuse: the gather of step i - NOBJ must be done.  It normally is, long ago: then nothing is put into the
-            # launch stream (a stream-wait marker between two launches costs the dependent launch a few microseconds)
-            if not pending[s].is_completed():
-                pending[s].wait()
+            # buffer reuse: the gather of step i - NOBJ must be done.  This process runs NOBJ steps ahead of its GPU, so it is
+            # normally NOT done yet: the HOST waits for it here (the launch stream still holds NOBJ - 1 launches to run
+            # meanwhile) instead of putting a wait marker into the launch stream, which costs the launch behind it a few
+            # microseconds -- every step (tolfg_multi does the same: profiles/r05_native_multi.md, 11.9 -> 5.8 us of gather
+            # cost per step on the headline).  It also bounds how far the host runs ahead.
+            w = pending[s]
+            while not w.is_completed():
+                pass
         if B > 0:
             bt.eval(dXs[i % len(dXs)], dF, dG, obj=obj[s], B=B)     # the finalizing waves also write the objectives, contiguous
         if coll:
@@ -551,9 +555,9 @@ def stated_config_records(tol_amd, job, x_buffers, keep=None):
             recs[-1]["expected_scaling"] = {
                 "per_gpu_batch": {str(n): -(-G // n) for n in (1, 2, 4, 8)},
                 "launch_us_measured_on_one_gpu": {"1024": 38.1, "512": 23.8, "256": 16.0, "128": 12.4},
-                "collective_us_per_step": "11-13 (one-rank RCCL rehearsal, profiles/r04_bench_line_1rank_rccl.json: 39.2 -> 52.1 us per step)",
+                "collective_us_per_step": "5-7 (one-rank RCCL rehearsals, profiles/r05_native_multi.md; 11-13 in round 4, when a wait marker still went into the launch stream every step)",
                 "expect": "a single device-resident trajectory already costs 10.8-12.4 us (one wave's life), so 1024 trajectories over 8 GPUs "
-                          "(128 each) read ~1.7-3.4 x one GPU, not 8 x: strong scaling of a 25 MB launch is latency-bound; the weak-scaling "
+                          "(128 each) read ~2-2.6 x one GPU, not 8 x: strong scaling of a 25 MB launch is latency-bound; the weak-scaling "
                           "headline (8192 per GPU, 280 us launches) is the curve to read for bandwidth"}
     return recs
 
@@ -561,6 +565,8 @@ def stated_config_records(tol_amd, job, x_buffers, keep=None):
 def device_identity(torch, ordinal):
     """What tells one GPU from another: ordinal, name, PCI bus id (torch's device properties where they carry it, else the HIP
     runtime's hipDeviceGetPCIBusId), uuid where known."""
+    if not torch.cuda.is_available():
+        return {"device": None, "name": "no GPU", "pci_bus_id": None, "uuid": None, "cus": None}
     props = torch.cuda.get_device_properties(ordinal)
     bus = None
     if all(hasattr(props, a) for a in ("pci_domain_id", "pci_bus_id", "pci_device_id")):
@@ -582,7 +588,7 @@ def device_identity(torch, ordinal):
 def rank_evidence(torch, dist, job, args, banner):
     """What the N > 1 line needs to prove which devices ran: every rank's identity card, gathered on rank 0."""
     from tol_amd.distributed import shard_bounds
-    card = dict(device_identity(torch, torch.cuda.current_device()), rank=job.rank, local_rank=job.local, pid=os.getpid(),
+    card = dict(device_identity(torch, torch.cuda.current_device() if torch.cuda.is_available() else 0), rank=job.rank, local_rank=job.local, pid=os.getpid(),
                 host=os.uname().nodename)
     if args.global_batch > 0:
         card["shard"] = list(shard_bounds(args.global_batch, job.rank, job.world))
@@ -598,14 +604,22 @@ def rank_evidence(torch, dist, job, args, banner):
         rccl["torch_nccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
     except Exception:      # noqa: BLE001
         pass
+    return cards, seen, rccl, rank_problems(cards, seen, args.gpus, job.backend if job.collective else None)
+
+
+def rank_problems(cards, seen, gpus, backend):
+    """What makes a line unreportable: a process group of another size than --gpus; under RCCL, two ranks on one device (a
+    scaling point over fewer GPUs than it says); ranks missing or out of order."""
     problems = []
-    if seen != args.gpus:
-        problems.append(f"the process group has {seen} ranks, --gpus says {args.gpus}")
-    if job.collective and job.backend == "nccl":
-        ids = [(c["host"], c["pci_bus_id"] or ("ordinal %d" % c["device"])) for c in cards]
+    if seen != gpus:
+        problems.append(f"the process group has {seen} ranks, --gpus says {gpus}")
+    if [c.get("rank") for c in cards] != list(range(len(cards))) or len(cards) != seen:
+        problems.append(f"identity cards of ranks {[c.get('rank') for c in cards]} for a group of {seen}")
+    if backend == "nccl":
+        ids = [(c.get("host"), c.get("pci_bus_id") or ("ordinal %s" % c.get("device"))) for c in cards]
         if len(set(ids)) != len(ids):
             problems.append(f"the ranks do not sit on pairwise distinct devices: {ids}")
-    return cards, seen, rccl, problems
+    return problems
 
 
 def capture_stdout_begin():
@@ -818,12 +832,12 @@ def wait_for_pids(pids, seconds):
         alive = []
         for p in left:
             try:
-                os.kill(p, 0)
-                alive.append(p)
-            except ProcessLookupError:
+                with open(f"/proc/{p}/stat") as fh:              # "pid (comm) state ...": a zombie has let go of its GPU already
+                    state = fh.read().rsplit(")", 1)[1].split()[0]
+                if state != "Z":
+                    alive.append(p)
+            except (OSError, IndexError):
                 pass
-            except PermissionError:
-                alive.append(p)
         left = alive
         if left:
             time.sleep(0.05)

@@ -1,6 +1,7 @@
 /* batch_montecarlo_multi.c -- plain C99 use of the several-GPUs-one-process ABI (include/tolfg.h, section 4):
  * a Monte-Carlo batch of B loiter trajectories that differ in their shear wind, sharded over the GPUs named on the
- * command line, evaluated with one launch per device, the objectives all-gathered over RCCL.
+ * command line, evaluated with one launch per device, the objectives all-gathered over RCCL -- once synchronously, then in a
+ * pipelined loop (tolfg_multi_step / tolfg_multi_gather_wait).
  *
  *   gcc -std=c99 -O2 -I include examples/batch_montecarlo_multi.c -L tol_amd/lib -ltolfg -L /opt/rocm/lib -lamdhip64 \
  *       -Wl,-rpath,$PWD/tol_amd/lib -Wl,-rpath,/opt/rocm/lib -o mc_multi && ./mc_multi 1024 0 1 2 3 4 5 6 7
@@ -50,6 +51,25 @@ int main(int argc, char **argv)
     double *obj = (double *)malloc(sizeof(double) * (size_t)B), mean = 0.0;
     TK(tolfg_multi_gather_objectives(m, obj));     /* ncclAllGather over the devices; global trajectory order */
     TK(tolfg_multi_mean_objective(m, &mean));      /* ncclAllReduce of the per-device partial sums */
+
+    /* The same as a loop a Monte-Carlo driver would run: step i+1 is launched before the objectives of step i are asked for, so
+     * the gather of one step runs beside the launch of the next (four objective buffers in rotation inside the library). */
+    {
+        const int steps = 6;
+        unsigned long ticket[2];
+        double *last = (double *)malloc(sizeof(double) * (size_t)B);
+        int s, same = 1;
+        TK(tolfg_multi_step(m, NULL, 0, 1, &ticket[0]));
+        for (s = 1; s < steps; s++) {
+            TK(tolfg_multi_step(m, NULL, 0, 1, &ticket[s & 1]));
+            TK(tolfg_multi_gather_wait(m, ticket[(s - 1) & 1], last));      /* step s is already running */
+        }
+        TK(tolfg_multi_gather_wait(m, ticket[(steps - 1) & 1], last));
+        for (t = 0; t < B; t++) same = same && last[t] == obj[t];          /* the same x every step: the same objectives, bit for bit */
+        printf("pipelined %d steps, objectives %s\n", steps, same ? "identical" : "DIFFERENT");
+        free(last);
+        if (!same) return 2;
+    }
 
     double lo = obj[0], hi = obj[0];
     for (t = 0; t < B; t++) { if (obj[t] < lo) lo = obj[t]; if (obj[t] > hi) hi = obj[t]; }

@@ -94,3 +94,50 @@ def test_a_process_group_of_another_size_than_gpus_is_refused():
                          timeout=300, env=env, cwd=ROOT)
     assert res.returncode == 2 and "WORLD_SIZE" in res.stderr
     assert not [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_what_makes_a_line_unreportable():
+    """bench.rank_problems: the checks behind exit code 4, on made-up identity cards."""
+    sys.path.insert(0, ROOT)
+    import bench
+    card = lambda r, bus, host="n0": {"rank": r, "device": r, "pci_bus_id": bus, "host": host}      # noqa: E731
+    good = [card(r, "0000:%02x:00.0" % (0x10 + r)) for r in range(8)]
+    assert bench.rank_problems(good, 8, 8, "nccl") == []
+    assert any("--gpus says 4" in p for p in bench.rank_problems(good, 8, 4, "nccl"))
+    twice = good[:7] + [card(7, good[0]["pci_bus_id"])]
+    assert any("pairwise distinct" in p for p in bench.rank_problems(twice, 8, 8, "nccl"))
+    assert bench.rank_problems(twice, 8, 8, "gloo") == []                 # a gloo rehearsal may share GPUs
+    other_host = good[:7] + [card(7, good[0]["pci_bus_id"], host="n1")]   # the same bus id on another host is another device
+    assert bench.rank_problems(other_host, 8, 8, "nccl") == []
+    assert any("identity cards" in p for p in bench.rank_problems(good[:7], 8, 8, "nccl"))
+    no_bus = [dict(card(r, None)) for r in range(2)]                      # no bus id known: the ordinals tell them apart
+    assert bench.rank_problems(no_bus, 2, 2, "nccl") == []
+    assert bench.rank_problems([card(0, None)], 1, 1, None) == []
+
+
+def test_rank_zero_waits_for_the_other_ranks_to_be_gone():
+    sys.path.insert(0, ROOT)
+    import bench
+    child = subprocess.Popen([sys.executable, "-c", "import time; time.sleep(0.4)"])
+    left = bench.wait_for_pids([os.getpid(), child.pid], 5.0)           # its own pid is not waited for
+    assert left == [] and child.poll() is not None
+    sleeper = subprocess.Popen([sys.executable, "-c", "import time; time.sleep(5)"])
+    try:
+        assert bench.wait_for_pids([sleeper.pid], 0.2) == [sleeper.pid]  # bounded: it says who is still there
+    finally:
+        sleeper.kill()
+        sleeper.wait()
+
+
+def test_the_native_leg_without_a_gpu_yields_a_record_that_says_so():
+    """The native C++ leg is a child process: whatever happens in it, the parent gets a record (and prints its own line)."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("this check is for hosts without a GPU")
+    sys.path.insert(0, ROOT)
+    import argparse
+    import bench
+    args = argparse.Namespace(steps=2, warmup=1, batch=8, ts=20, mission="S10", aircraft="tempest", dtype="f64", x_buffers=1, global_batch=0,
+                              no_configs=True)
+    rec = bench.run_native_child(1, args, "grouped", timeout=300)
+    assert "error" in rec and "visible" in rec["error"] and rec["child_exit_code"] == 1 and rec["n_gpus"] == 1

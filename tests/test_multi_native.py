@@ -107,6 +107,7 @@ def test_c_example_runs_on_one_device(tolfg, oracle, tmp_path):
     B = 41
     out = subprocess.run([exe, str(B), "0"], capture_output=True, text=True, timeout=180)
     assert out.returncode == 0, out.stdout + out.stderr
+    assert "pipelined 6 steps, objectives identical" in out.stdout
     w = out.stdout.split()
     first, last, mean = float(w[w.index("first") + 1]), float(w[w.index("last") + 1]), float(w[w.index("mean") + 1])
     vals = []

@@ -68,6 +68,7 @@ void parse(Knobs &k, bool announce)
     if (env_int("TOLFG_PLACE_FAIL_AT", 0, 64, &v)) k.place_fail_at = v;
     if (env_int("TOLFG_PLACE_SETTLE", 0, 1, &v)) k.place_settle = v;
     if (env_int("TOLFG_MULTI_GATHER_PRIORITY", 0, 1, &v)) k.multi_gather_priority = v;
+    if (const char *e = std::getenv("TOLFG_MULTI_SLOT_WAIT")) k.multi_slot_wait_on_host = std::strcmp(e, "stream") != 0;
     if (const char *e = std::getenv("TOLFG_CALLBACK_STAGING")) k.callback_staging = e[0] == '1';
     if (const char *e = std::getenv("TOLFG_ZERO_COPY_LIMIT")) k.zero_copy_limit = std::atol(e);
     if (env_int("TOLFG_CHUNKS", 1, 6, &v)) k.chunks = v;

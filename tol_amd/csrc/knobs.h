@@ -31,6 +31,8 @@
 //     TOLFG_PLACE_SETTLE=0|1          0 = device_alloc hands a fresh block out at once (round 4's form: the driver's pending wipe may
 //                                     zero what is written to it); 1 = it settles the block first (problem.cpp: settle_block)
 //     TOLFG_MULTI_GATHER_PRIORITY=0|1 tolfg_multi's gather streams at the lowest | the highest (default) stream priority
+//     TOLFG_MULTI_SLOT_WAIT=host|stream  tolfg_multi, an objective buffer still read by the gather of four steps back: the issuing thread
+//                                     waits for it (host, default) | a wait marker goes into the launch stream (stream)
 //     TOLFG_CALLBACK_STAGING=1        the callback through explicit H2D / D2H copies instead of host-mapped arrays
 //     TOLFG_ZERO_COPY_LIMIT=bytes     size of x+F+G up to which the callback addresses host memory directly
 //     TOLFG_CHUNKS=1..6               pieces of G's device-to-host copy on the staged path
@@ -63,6 +65,7 @@ struct Knobs {
     int  place_fail_at = -1;
     int  place_settle = 1;
     int  multi_gather_priority = 1;
+    bool multi_slot_wait_on_host = true;
     bool callback_staging = false;
     long zero_copy_limit = -1;       // -1 = the library's (64 MB)
     int  chunks = -1;                // -1 = the library's (2)

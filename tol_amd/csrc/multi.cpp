@@ -452,7 +452,12 @@ void multi::part_eval(Part &p, int slot, bool needF, bool needG, const void *X)
         const hipError_t q = hipEventQuery(p.ev_gather[slot]);
         if (q == hipErrorNotReady) {
             clear_hip_errors();
-            check(hipStreamWaitEvent(p.stream, p.ev_gather[slot], 0), "hipStreamWaitEvent(slot reuse)");
+            // The issuing thread is kSlots steps ahead of its device.  It waits HERE, on the host, for that gather: the launch
+            // stream still holds kSlots - 1 launches to run meanwhile, and gets no wait marker (which would cost every launch of a
+            // host that runs ahead -- every host does -- a few microseconds: profiles/r05_native_multi.md).  It also bounds how far
+            // the host runs ahead of the devices.
+            if (knobs().multi_slot_wait_on_host) check(hipEventSynchronize(p.ev_gather[slot]), "hipEventSynchronize(slot reuse)");
+            else check(hipStreamWaitEvent(p.stream, p.ev_gather[slot], 0), "hipStreamWaitEvent(slot reuse)");
         } else if (q != hipSuccess) {
             check(q, "hipEventQuery");
         }

@@ -104,7 +104,7 @@ struct DeviceBlock {
 };
 std::mutex g_blocks_mu;
 std::map<void *, DeviceBlock> g_blocks;
-void note_freed(size_t bytes);       // settle_block's bookkeeping, below
+void note_freed(int device, size_t bytes);       // settle_block's bookkeeping, below
 
 void release_block(void *ptr, DeviceBlock &b)
 {
@@ -115,7 +115,7 @@ void release_block(void *ptr, DeviceBlock &b)
     (void)hipMemUnmap(ptr, b.bytes);
     for (hipMemGenericAllocationHandle_t h : b.handles) (void)hipMemRelease(h);
     (void)hipMemAddressFree(ptr, b.bytes);
-    note_freed(b.bytes);          // the driver wipes what it gets back, later: the next device_alloc waits accordingly (settle_block)
+    note_freed(b.device, b.bytes);          // the driver wipes what it gets back, later: the next device_alloc waits accordingly (settle_block)
 }
 }  // namespace
 
@@ -128,28 +128,31 @@ namespace {
 // Zeroing the block first does not help, waiting for the chunks' fences through a dma-buf poll does not either, blocks allocated
 // without a free before them are (all but) safe, and hipMalloc never shows it.  So the allocator settles a block before it hands it
 // out: the block is filled with a pattern and must still hold it, every word, through a quiet period -- what a copy engine at a
-// conservative 10 GB/s needs for this block plus everything this library freed during the last second, at least 1 ms; a word that
+// conservative 10 GB/s needs for this block plus everything this library freed on the device during the last second, at least 1 ms; a word that
 // went back to zero restarts the wait.  450 back-to-back allocations after frees: none lost a write (against 40-90 % without).
 // Cost: one fill and a few reads of the block, and the quiet period: ~1.5 ms for a small block, ~0.1 s per GB: set-up time.
 constexpr unsigned kSettlePattern = 0xA5C35A3Cu;
 using settle_clock = std::chrono::steady_clock;
 std::mutex g_freed_mu;
-std::vector<std::pair<settle_clock::time_point, size_t>> g_freed;       // what device_free gave back to the driver lately
+std::map<int, std::vector<std::pair<settle_clock::time_point, size_t>>> g_freed;       // per device: what device_free gave back to the driver lately
 
-void note_freed(size_t bytes)
+void note_freed(int device, size_t bytes)
 {
     std::lock_guard<std::mutex> lk(g_freed_mu);
+    auto &v = g_freed[device];
     const auto now = settle_clock::now();
-    g_freed.emplace_back(now, bytes);
-    while (!g_freed.empty() && now - g_freed.front().first > std::chrono::seconds(1)) g_freed.erase(g_freed.begin());
+    v.emplace_back(now, bytes);
+    while (!v.empty() && now - v.front().first > std::chrono::seconds(1)) v.erase(v.begin());
 }
 
-size_t freed_lately()
+size_t freed_lately(int device)
 {
     std::lock_guard<std::mutex> lk(g_freed_mu);
+    const auto it = g_freed.find(device);
+    if (it == g_freed.end()) return 0;
     const auto now = settle_clock::now();
     size_t sum = 0;
-    for (const auto &f : g_freed)
+    for (const auto &f : it->second)
         if (now - f.first <= std::chrono::seconds(1)) sum += f.second;
     return sum;
 }
@@ -159,7 +162,7 @@ void settle_block(void *ptr, const DeviceBlock &b)
     unsigned long long *count = nullptr;
     check(hipHostMalloc(reinterpret_cast<void **>(&count), sizeof *count, hipHostMallocDefault), "hipHostMalloc(settle)");
     struct Free { void *p; ~Free() { (void)hipHostFree(p); } } guard{count};
-    const double quiet_ms = std::min(2000.0, std::max(1.0, (double)(b.bytes + freed_lately()) / 10e6));
+    const double quiet_ms = std::min(2000.0, std::max(1.0, (double)(b.bytes + freed_lately(b.device)) / 10e6));
     const auto nap = std::chrono::microseconds((long)std::min(5000.0, std::max(200.0, 1e3 * quiet_ms / 20)));
     const auto deadline = settle_clock::now() + std::chrono::milliseconds(3000 + (long)(4 * quiet_ms));
     for (;;) {

@@ -15,10 +15,12 @@ import tol_amd    # noqa: E402
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 for what, mission, air, total, dtype in (("mixed 8192 f64", "mixed", bench.AIRCRAFT5, 8192, "f64"), ("S10 1024 f64", "S10", ("tempest",), 1024, "f64"),
                                          ("S10 128 f64", "S10", ("tempest",), 128, "f64")):
-    for prio, issue, gather in (("1", "grouped", "rccl"), ("1", "threads", "rccl"), ("0", "grouped", "rccl"), ("1", "grouped", "host"), ("1", "threads", "host")):
+    for prio, issue, gather, slot_wait in (("1", "grouped", "rccl", "host"), ("1", "grouped", "rccl", "stream"), ("1", "threads", "rccl", "host"), ("1", "threads", "rccl", "stream"),
+                                           ("0", "grouped", "rccl", "host"), ("1", "grouped", "host", "host"), ("1", "threads", "host", "host")):
         if True:
             os.environ["TOLFG_MULTI_GATHER_PRIORITY"] = prio
+            os.environ["TOLFG_MULTI_SLOT_WAIT"] = slot_wait
             r = bench.native_workload(tol_amd, torch, [0], mission, air, 200, dtype, total, steps, 10, 4, issue, "weak", what, gather=gather)
-            print(f"{what:15s} gather {gather:4s} (stream priority {'high' if prio == '1' else 'low '}) issue {issue:7s}: step {1e3 * r['ms_per_step']:7.1f} us with the gather, "
+            print(f"{what:15s} gather {gather:4s} (stream priority {'high' if prio == '1' else 'low '}) issue {issue:7s} slot wait on {slot_wait:6s}: step {1e3 * r['ms_per_step']:7.1f} us with the gather, "
                   f"{1e3 * r['ms_per_step_without_gather']:7.1f} without (launch stream: {r['eval_us']:7.1f} / {r['eval_us_without_gather']:7.1f} us per launch); "
                   f"host issue {r['issue_us_per_step']:5.1f} us per step; one synchronous gather {r['gather_us']:5.1f} us", flush=True)
