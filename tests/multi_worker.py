@@ -82,6 +82,16 @@ def pipeline(out, mission, dtype, total, parts, N, issue, gather="rccl"):
         sync.append(m.gather_objectives())
     res["obj_sync"] = np.stack(sync)
     res["mean_last"] = np.array(m.mean_objective())
+    # a longer run over the rotating objective buffers: 400 steps, the host three tickets behind the step it issues (the slot-reuse
+    # wait is exercised every step), every gathered vector compared with the synchronous one of its input set
+    lag, bad, tk = tolfg.capi.MULTI_SLOTS - 1, 0, []
+    for j in range(400):
+        tk.append(m.step(dX=sets[j % nsteps]))
+        if j >= lag:
+            bad += not np.array_equal(m.gather_wait(tk[j - lag]), sync[(j - lag) % nsteps])
+    for j in range(400 - lag, 400):
+        bad += not np.array_equal(m.gather_wait(tk[j]), sync[j % nsteps])
+    res["soak_mismatches"] = np.array(bad)
     # the native step loop, with and without the gather; then the object still works
     tim = [m.time_steps(12, warm=3, x_sets=sets[:5]), m.time_steps(12, warm=3, x_sets=sets[:5], gather=False), m.time_steps(5, warm=0)]
     res["timing"] = np.array(json.dumps(tim))

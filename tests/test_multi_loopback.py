@@ -134,6 +134,7 @@ def test_asynchronous_gather_equals_the_synchronous_one(tolfg, tmp_path, mission
     assert np.array_equal(r["obj_run_last"], s[int(r["run_last_set"])])
     tol = 1e-12 if dtype == "f64" else 1e-6
     assert float(r["mean_last"]) == pytest.approx(float(s[-1].astype(np.float64).mean()), rel=tol)
+    assert int(r["soak_mismatches"]) == 0                                  # 400 pipelined steps, the host three gathers behind
     assert np.array_equal(r["obj_after_loop"], s[1])
     assert np.array_equal(r["obj_other_gather"], s[2])
     assert float(r["mean_other_gather"]) == pytest.approx(float(s[2].astype(np.float64).mean()), rel=tol)
