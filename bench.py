@@ -800,7 +800,7 @@ def run_native_child(n, args, issue="grouped", timeout=600):
            "--aircraft", args.aircraft, "--dtype", args.dtype, "--x-buffers", str(args.x_buffers), "--min-warm-seconds", str(MIN_WARM_S)]
     if args.global_batch > 0:
         cmd += ["--global-batch", str(args.global_batch)]
-    if args.no_configs or issue != "grouped":
+    if args.no_configs:
         cmd.append("--no-configs")
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK",
                                                            "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID", "OMP_NUM_THREADS")}
@@ -1116,8 +1116,9 @@ def main():
                 nm["note_devices"] = f"{world} ranks, {ndev} device(s) visible to rank 0: the native leg ran over {n_native}"
             line["native_multi"] = nm
             if n_native > 1 and "error" not in nm:
-                # the other way of issuing the collective (one call per device thread), headline only, in a process of its own
-                line["native_multi_threads"] = run_native_child(n_native, args, "threads", timeout=300)
+                # the other way of issuing the collective (one call per device thread: no rendezvous of the host threads per step,
+                # which is what a 12 us launch per device wants), in a process of its own
+                line["native_multi_threads"] = run_native_child(n_native, args, "threads", timeout=600)
         sys.stdout.flush()
         data = (json.dumps(line) + "\n").encode()
         while data:

@@ -97,6 +97,28 @@ def pipeline(out, mission, dtype, total, parts, N, issue, gather="rccl"):
     res["timing"] = np.array(json.dumps(tim))
     m.eval_from(sets[1])
     res["obj_after_loop"] = m.gather_objectives()
+    # One device's launch refuses to start (an earlier evaluation of its shard lost an objective partial: an x that carries the
+    # empty-slot marker) while the other devices' launches and their calls of the collective go ahead: the step must come back
+    # with the error -- no device left waiting for a rank that never joins -- and the next step must work.
+    if mission == "mixed":
+        marker = np.array([0xFFFBADADFFFBADAD], dtype=np.uint64).view(np.float64)[0]
+        part = 2
+        lo, hi = m.shard(part)
+        (dXp, ldx), _, _ = m.buffers(part)
+        poisoned = keep[part].clone()                                  # set 0's rows of that part
+        poisoned[1, 1 + 11 * 7 + 10] = float(marker)                   # thrust of node 7 of its second trajectory
+        assert poisoned[1, 1 + 11 * 7 + 10].view(torch.int64).item() == np.float64(marker).view(np.int64)
+        bad_set = list(sets[0])
+        bad_set[part] = poisoned.data_ptr()
+        torch.cuda.synchronize()
+        m.step(dX=bad_set)                                             # runs; that shard's status word gets set
+        m.sync()
+        try:
+            m.step(dX=sets[0])                                         # part 2 refuses (lost partial pending), the others launch and gather
+            res["refusal"] = np.array("no error")
+        except tolfg.TolfgError as e:
+            res["refusal"] = np.array(f"{e.code} {e}")
+        res["obj_after_refusal"] = m.gather_wait(m.step(dX=sets[0]))
     # the other way of gathering on the same object: the same numbers
     m.set_gather("host" if gather == "rccl" else "rccl")
     res["obj_other_gather"] = m.gather_wait(m.step(dX=sets[2]))

@@ -5,6 +5,7 @@
 
 #include <chrono>
 #include <cstdlib>
+#include <exception>
 #include <cstring>
 #include <stdexcept>
 
@@ -534,8 +535,12 @@ unsigned long multi::step(bool needF, bool needG, const void *const *dX)
     // one wake-up of the issuing threads per step: every thread issues its launch and its part of the gather
     const int slot = (int)(seq_ % kSlots);
     on_every_device([&](Part &p) {
-        part_eval(p, slot, needF, needG, dX ? dX[p.index] : nullptr);
+        // a device whose launch fails still makes its call of the collective: the other devices' calls are on their way, and
+        // a collective one rank never joins would leave their kernels waiting for ever
+        std::exception_ptr failed;
+        try { part_eval(p, slot, needF, needG, dX ? dX[p.index] : nullptr); } catch (...) { failed = std::current_exception(); }
         part_gather_pre(p, slot); part_gather_call(p, slot); part_gather_post(p, slot);
+        if (failed) std::rethrow_exception(failed);
     });
     last_gather_slot_ = slot;
     evaluated_since_gather_ = false;
@@ -630,12 +635,16 @@ void multi::steps_run(int n, int n_x, const void *const *dX, bool needF, bool ne
         // without meeting the other threads on the host: the collective's kernels meet on the devices
         const unsigned long seq0 = seq_;
         on_every_device([&](Part &p) {
+            std::exception_ptr failed;      // a device that fails keeps joining the collectives of the remaining steps (see step())
             for (int i = 0; i < n; ++i) {
                 const int slot = (int)((seq0 + (unsigned long)i) % kSlots);
                 const void *X = n_x > 0 ? dX[(size_t)((first_step + (unsigned long)i) % (unsigned long)n_x) * world + p.index] : nullptr;
-                part_eval(p, slot, needF, needG, X);
+                if (!failed) {
+                    try { part_eval(p, slot, needF, needG, X); } catch (...) { failed = std::current_exception(); }
+                }
                 part_gather_pre(p, slot); part_gather_call(p, slot); part_gather_post(p, slot);
             }
+            if (failed) std::rethrow_exception(failed);
         });
         seq_ += (unsigned long)n;
         if (n > 0) { last_gather_slot_ = (int)((seq_ - 1) % kSlots); evaluated_since_gather_ = false; }
