@@ -162,6 +162,12 @@ def main():
     # a second evaluation + gather: the collectives are re-entrant and the partial slots were emptied
     m.eval()
     res["obj_again"] = m.gather_objectives()
+    # the other way of gathering (the finalizing waves store into one pinned host vector), empty shards included
+    m.set_gather("host")
+    m.eval()
+    res["obj_host"] = m.gather_objectives()
+    res["mean_host"] = np.array(m.mean_objective())
+    m.set_gather("rccl")
     for i in range(parts):
         lo, hi = m.shard(i)
         if hi > lo:

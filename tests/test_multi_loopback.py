@@ -93,7 +93,8 @@ def test_several_parts_on_one_device(tolfg, oracle, tmp_path, mission, dtype, to
                                    f"{[(got[tuple(b)], want[tuple(b)]) for b in bad[:6]]}")
     # gathered objectives: global order, equal to the single batch's F[:, 0]; the second gather too
     assert r["obj"].shape == (total,)
-    assert np.array_equal(r["obj"], F1[:, 0]) and np.array_equal(r["obj_again"], F1[:, 0])
+    assert np.array_equal(r["obj"], F1[:, 0]) and np.array_equal(r["obj_again"], F1[:, 0]) and np.array_equal(r["obj_host"], F1[:, 0])
+    assert float(r["mean_host"]) == pytest.approx(float(F1[:, 0].astype(np.float64).mean()), rel=1e-12 if dtype == "f64" else 1e-6)
     assert float(r["mean"]) == pytest.approx(float(F1[:, 0].astype(np.float64).mean()), rel=1e-12 if dtype == "f64" else 1e-6)
     # and against the oracle
     if dtype == "f64":
