@@ -1003,6 +1003,13 @@ def main():
     keep = {}        # the headline's batch and buffers: re-used by a stated config of the same workload (one GPU: configs[4] fp64)
     r = sharded_run(tol_amd, job, args.mission, aircraft, args.ts, args.dtype, args.pattern,
                     0 if args.global_batch > 0 else args.batch, args.global_batch, args.steps, args.warmup, args.x_buffers, keep=keep)
+    # where every rank's output buffer landed (the placement search of its G buffer): onto its identity card
+    placements = [r["placement"]]
+    if coll:
+        placements = [None] * world
+        dist.all_gather_object(placements, r["placement"])
+    for card, pl in zip(cards, placements):
+        card["placement"] = {"candidates": pl.get("candidates"), "probe_us": pl.get("probe_us")} if pl else None
     configs = None
     if not args.no_configs:
         configs = stated_config_records(tol_amd, job, args.x_buffers, keep=keep)      # every rank takes part

@@ -305,6 +305,10 @@ int  tolfg_batch_objectives(tolfg_batch *b, int B, const void *dF, long ldf, voi
  *     how many were timed -- 1 and no timing when the launch's outputs fit the cache, where placement does not matter.
  *     Blocking, tens of ms: set-up time.  Free the buffer with tolfg_device_free.
  * Buffers from anywhere else keep working; they just take the class they land in. */
+/* A block comes SETTLED and zeroed: the driver wipes video memory it gets back with a copy job of its own and may hand the chunks out
+ * again before that job has run, so that a fresh block was seen to go back to 0.0, chunk by chunk, milliseconds after a kernel had
+ * written it (profiles/r05_fresh_vmm_blocks.md).  tolfg_device_alloc therefore fills the block with a pattern and returns only once the
+ * pattern has held through a quiet period (>= 1 ms; ~0.1 s per GB), synchronising the device while it does: call it at set-up time. */
 int  tolfg_device_alloc(int device, size_t bytes, void **ptr);
 int  tolfg_device_free(void *ptr);      /* waits for the device first, like hipFree does */
 int  tolfg_batch_alloc_outputs(tolfg_batch *b, int B, int tries, void **dG, long *ldg, double *probe_us, int *tried);

@@ -40,7 +40,7 @@ def test_plain_command_with_two_ranks_prints_one_line(tmp_path):
     B = line["config"]["batch_per_gpu"]
     assert line["world_seen"] == 2 and [c["rank"] for c in line["ranks"]] == [0, 1]
     assert [c["shard"] for c in line["ranks"]] == [[0, B], [B, 2 * B]]
-    assert all(c["name"] and c["pid"] > 0 and "device" in c and "pci_bus_id" in c for c in line["ranks"])
+    assert all(c["name"] and c["pid"] > 0 and "device" in c and "pci_bus_id" in c and c["placement"]["candidates"] >= 1 for c in line["ranks"])
     assert len({c["pid"] for c in line["ranks"]}) == 2
     cfg3 = [r for r in line["configs"] if r["config"] == 3][0]
     assert cfg3["expected_scaling"]["per_gpu_batch"]["8"] == 128

@@ -104,3 +104,51 @@ def test_host_setup_under_asan_ubsan(tmp_path):
     res = subprocess.run([exe, data], capture_output=True, text=True, env=ENV, timeout=300)
     assert res.returncode == 0, res.stdout + res.stderr
     assert "rc=0" in res.stdout
+
+
+KNOBS_DRIVER = r'''
+#include <cstdio>
+#include <cstdlib>
+#include "knobs.h"
+using namespace tolfg;
+int main() {
+    int rc = 0;
+    const Knobs &k = knobs();
+    if (measurement_build()) {
+        // the measurement build: what the environment said when the process started ...
+        if (k.fused != 0 || k.tile_nodes != 128 || k.tail_count != 7 || k.tail_nt != 16 || !k.no_flag || k.place_settle != 0 || k.multi_slot_wait_on_host) rc = 1;
+        if (k.rccl_library != "/nowhere/librccl.so" || !k.multi_shared_devices || !k.trace) rc = 2;
+        // ... and again whenever an object is created
+        setenv("TOLFG_FUSED", "1", 1); unsetenv("TOLFG_TILE_NODES"); setenv("TOLFG_WAVES_PER_CU", "99", 1); setenv("TOLFG_RCCL_LIBRARY", "/elsewhere", 1);
+        refresh_knobs();
+        if (k.fused != 1 || k.tile_nodes != -1 || k.waves_per_cu != 32) rc = 3;
+        if (k.rccl_library != "/nowhere/librccl.so") rc = 4;           // the collective library is chosen once per process
+    } else {
+        // the shipped build: three variables, nothing else, never again
+        if (k.fused != -1 || k.tile_nodes != -1 || k.tail_count != -1 || k.no_flag || k.place_settle != 1 || !k.multi_slot_wait_on_host) rc = 5;
+        if (k.rccl_library != "/nowhere/librccl.so" || !k.multi_shared_devices || !k.trace) rc = 6;
+        setenv("TOLFG_TRACE", "0", 1);
+        refresh_knobs();
+        if (!k.trace) rc = 7;
+    }
+    std::printf("knobs run rc=%d\\n", rc);
+    return rc;
+}
+'''
+
+
+def test_knobs_under_asan_ubsan(tmp_path):
+    """tol_amd/csrc/knobs.cpp, both builds: the shipped one reads three variables once; the measurement build the whole table, again
+    at every refresh -- except the collective library, which is chosen once per process."""
+    src = tmp_path / "knobs_san.cpp"
+    src.write_text(KNOBS_DRIVER)
+    csrc = os.path.join(ROOT, "tol_amd", "csrc")
+    env = dict(ENV, TOLFG_FUSED="0", TOLFG_TILE_NODES="128", TOLFG_TAIL="7:16", TOLFG_NO_FLAG="1", TOLFG_PLACE_SETTLE="0", TOLFG_MULTI_SLOT_WAIT="stream",
+               TOLFG_RCCL_LIBRARY="/nowhere/librccl.so", TOLFG_MULTI_SHARED_DEVICES="1", TOLFG_TRACE="1")
+    for flags in ([], ["-DTOLFG_MEASURE"]):
+        exe = str(tmp_path / ("knobs_san" + ("_measure" if flags else "")))
+        subprocess.run(["g++", "-std=c++17", *SAN, *flags, "-I", csrc, str(src), os.path.join(csrc, "knobs.cpp"), "-o", exe, "-lpthread"], check=True)
+        res = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=120)
+        assert res.returncode == 0 and "rc=0" in res.stdout, res.stdout + res.stderr
+        assert "test seam active" in res.stderr                   # the seam announces itself, once
+        assert res.stderr.count("test seam active") == 1
