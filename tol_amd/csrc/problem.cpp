@@ -112,7 +112,9 @@ void release_block(void *ptr, DeviceBlock &b)
     if (b.chunk == 0) { (void)hipFree(ptr); return; }
     // hipFree waits for the device by itself; unmapping does not, and a launch still writing the range would fault
     (void)hipDeviceSynchronize();
-    (void)hipMemUnmap(ptr, b.bytes);
+    // every chunk unmapped the way it was mapped, one mapping at a time (one hipMemUnmap over the whole range leans on the runtime
+    // splitting it over the mappings it covers)
+    for (size_t i = 0; i < b.handles.size(); ++i) (void)hipMemUnmap(static_cast<char *>(ptr) + i * b.chunk, b.chunk);
     for (hipMemGenericAllocationHandle_t h : b.handles) (void)hipMemRelease(h);
     (void)hipMemAddressFree(ptr, b.bytes);
     note_freed(b.device, b.bytes);          // the driver wipes what it gets back, later: the next device_alloc waits accordingly (settle_block)
@@ -231,7 +233,7 @@ void *device_alloc(int device, size_t bytes)
             try { settle_block(ptr, blk); } catch (const std::exception &e) { ok = false; why = e.what(); }
         }
         if (!ok) {             // out of memory or an unsupported step: undo, report
-            if (mapped) (void)hipMemUnmap(ptr, mapped);
+            for (size_t off = 0; off < mapped; off += kPlacedChunk) (void)hipMemUnmap(static_cast<char *>(ptr) + off, kPlacedChunk);
             for (hipMemGenericAllocationHandle_t h : blk.handles) (void)hipMemRelease(h);
             (void)hipMemAddressFree(ptr, blk.bytes);
             clear_errors();
