@@ -100,7 +100,7 @@ def pipeline(out, mission, dtype, total, parts, N, issue, gather="rccl"):
     # One device's launch refuses to start (an earlier evaluation of its shard lost an objective partial: an x that carries the
     # empty-slot marker) while the other devices' launches and their calls of the collective go ahead: the step must come back
     # with the error -- no device left waiting for a rank that never joins -- and the next step must work.
-    if mission == "mixed":
+    if mission == "mixed" and os.environ.get("TOLFG_FUSED") != "0":       # (the two-launch form, a measurement override, has no polled slots)
         marker = np.array([0xFFFBADADFFFBADAD], dtype=np.uint64).view(np.float64)[0]
         part = 2
         lo, hi = m.shard(part)
