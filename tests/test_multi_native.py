@@ -158,3 +158,34 @@ def test_wind_reaches_every_shard(tolfg, oracle, wind):
     torch.cuda.synchronize()
     assert not torch.equal(rG[:, :ref.neG], dG[:, :bt.neG])
     m.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("issue,gather", [("grouped", "rccl"), ("threads", "rccl"), ("grouped", "host"), ("threads", "host")])
+def test_pipelined_steps_through_the_real_rccl_calls(tolfg, issue, gather):
+    """tolfg_multi_step / gather_wait on one device with the real library: ncclAllGather on the gather stream (inside a group
+    bracket, or as a plain call from the device's thread), or no collective at all (objectives stored to the pinned host vector);
+    the native step loop; the same objectives as the synchronous gather every time."""
+    B = 40
+    trajs = [tolfg.Trajectory(aircraft=t % 2, radius_goal=100.0, Vref=0.3 * t, href=9.0, xi=2.0 * t, yi=-1.0 * t, zi=-40.0 - t) for t in range(B)]
+    m = tolfg.Multi("S10", ["tempest", "skywalker"], ts=100, devices=[0])
+    m.set_issue(issue)
+    m.set_gather(gather)
+    m.set_trajectories(trajs)
+    m.x0()
+    m.eval()
+    want = m.gather_objectives()
+    assert np.isfinite(want).all() and want[0] != want[1]
+    tickets = [m.step() for _ in range(3)]                      # three steps in flight, nobody waiting
+    got = [m.gather_wait(t) for t in tickets]
+    for _ in range(10):                                         # beyond the four rotating buffers, one ticket behind
+        tickets.append(m.step())
+        got.append(m.gather_wait(tickets[-2]))
+    got.append(m.gather_wait(tickets[-1]))
+    assert all(np.array_equal(g, want) for g in got)
+    t = m.time_steps(30, warm=5)
+    assert t["issue"] == issue and t["gather"] == gather and t["wall_us_per_step"] > 0 and t["gather_us"] > 0
+    assert m.mean_objective() == pytest.approx(float(want.mean()), rel=1e-12)
+    with pytest.raises(tolfg.TolfgError):
+        m.gather_wait(tickets[0])                               # long expired
+    m.close()
