@@ -791,7 +791,7 @@ def native_multi_main(args):
     return 0 if "error" not in out else 1
 
 
-def run_native_child(n, args, issue="grouped", timeout=600):
+def run_native_child(n, args, issue="grouped", timeout=420):
     """Start `bench.py --native-multi n` as a CHILD process (never an exec: this process has initialised the GPU) and return its
     record, or a record that says why there is none."""
     import subprocess
@@ -1125,7 +1125,7 @@ def main():
             if n_native > 1 and "error" not in nm:
                 # the other way of issuing the collective (one call per device thread: no rendezvous of the host threads per step,
                 # which is what a 12 us launch per device wants), in a process of its own
-                line["native_multi_threads"] = run_native_child(n_native, args, "threads", timeout=600)
+                line["native_multi_threads"] = run_native_child(n_native, args, "threads", timeout=300)
         sys.stdout.flush()
         data = (json.dumps(line) + "\n").encode()
         while data:

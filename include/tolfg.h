@@ -379,7 +379,9 @@ int  tolfg_multi_gather_wait(tolfg_multi *m, unsigned long ticket, void *host_ob
 int  tolfg_multi_step(tolfg_multi *m, const void *const *dX, int n_devices, int needG, unsigned long *ticket);
 /* How the collective is issued.  GROUPED (default): one ncclGroupStart / ncclGroupEnd bracket around the devices' calls,
  * from the caller's thread.  THREADS: every device's issuing thread calls for its own communicator, no group (NCCL's
- * one-thread-per-device form); a tolfg_multi_step then needs no rendezvous of the host threads.  Same results. */
+ * one-thread-per-device form); a tolfg_multi_step then needs no rendezvous of the host threads.  Same results.  The bracket is
+ * serial work of ~18 us per device for the calling thread (150 us per step at 8 devices, against <= 45 us per thread):
+ * choose THREADS -- or TOLFG_MULTI_GATHER_HOST -- when a device's launch is shorter than that (profiles/r05_native_multi.md). */
 enum { TOLFG_MULTI_ISSUE_GROUPED = 0, TOLFG_MULTI_ISSUE_THREADS = 1 };
 int  tolfg_multi_set_issue(tolfg_multi *m, int mode);
 /* Where the objectives are gathered.  RCCL (default): ncclAllGather into a device vector on every device.  HOST: no collective

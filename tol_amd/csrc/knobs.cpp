@@ -72,6 +72,7 @@ void parse(Knobs &k, bool announce)
     if (const char *e = std::getenv("TOLFG_CALLBACK_STAGING")) k.callback_staging = e[0] == '1';
     if (const char *e = std::getenv("TOLFG_ZERO_COPY_LIMIT")) k.zero_copy_limit = std::atol(e);
     if (env_int("TOLFG_CHUNKS", 1, 6, &v)) k.chunks = v;
+    k.multi_solo_comms = env_set("TOLFG_MULTI_SOLO_COMMS");
     k.no_register = env_set("TOLFG_NO_REGISTER");
     k.no_flag = env_set("TOLFG_NO_FLAG");
     k.callback_copy_x = env_set("TOLFG_CALLBACK_COPY_X");

@@ -33,6 +33,9 @@
 //     TOLFG_MULTI_GATHER_PRIORITY=0|1 tolfg_multi's gather streams at the lowest | the highest (default) stream priority
 //     TOLFG_MULTI_SLOT_WAIT=host|stream  tolfg_multi, an objective buffer still read by the gather of four steps back: the issuing thread
 //                                     waits for it (host, default) | a wait marker goes into the launch stream (stream)
+//     TOLFG_MULTI_SOLO_COMMS=1        tolfg_multi: every part its own one-rank communicator, a device may appear more than once: several
+//                                     parts on one GPU under the REAL library, for timing the host side of a step (the gathered vectors
+//                                     then hold the part's own block only)
 //     TOLFG_CALLBACK_STAGING=1        the callback through explicit H2D / D2H copies instead of host-mapped arrays
 //     TOLFG_ZERO_COPY_LIMIT=bytes     size of x+F+G up to which the callback addresses host memory directly
 //     TOLFG_CHUNKS=1..6               pieces of G's device-to-host copy on the staged path
@@ -66,6 +69,7 @@ struct Knobs {
     int  place_settle = 1;
     int  multi_gather_priority = 1;
     bool multi_slot_wait_on_host = true;
+    bool multi_solo_comms = false;
     bool callback_staging = false;
     long zero_copy_limit = -1;       // -1 = the library's (64 MB)
     int  chunks = -1;                // -1 = the library's (2)

@@ -142,7 +142,7 @@ multi::multi(const std::string &mission, const std::string &root, const std::vec
     // Test seam (knobs.h): with the shared-devices variable AND an explicit stand-in collective library an ordinal may appear
     // more than once, so that several parts -- their issuing threads, shard dealing, per-shard uploads and the padded gather --
     // run on a box with ONE GPU (tests/loopback_nccl).  RCCL itself refuses duplicate devices in ncclCommInitAll.
-    if (!knobs().multi_shared_devices)
+    if (!knobs().multi_shared_devices && !knobs().multi_solo_comms)
         for (size_t i = 0; i < devices.size(); ++i)
             for (size_t j = 0; j < i; ++j)
                 if (devices[i] == devices[j]) throw std::invalid_argument("tolfg_multi: every device may appear once");
@@ -179,7 +179,13 @@ multi::multi(const std::string &mission, const std::string &root, const std::vec
         }
         const rccl_api &nc = rccl_api::get();
         std::vector<void *> comms(devices.size(), nullptr);
-        nccl_check(nc.CommInitAll(comms.data(), (int)devices.size(), devices.data()), "ncclCommInitAll");
+        if (knobs().multi_solo_comms) {
+            // measurement build only (knobs.h): every part a communicator of ONE rank, so that several parts can sit on one device
+            // under the real library -- the gathered vectors then hold only the part's own block: for timing the host side, nothing else
+            for (size_t i = 0; i < devices.size(); ++i) nccl_check(nc.CommInitAll(&comms[i], 1, &devices[i]), "ncclCommInitAll(solo)");
+        } else {
+            nccl_check(nc.CommInitAll(comms.data(), (int)devices.size(), devices.data()), "ncclCommInitAll");
+        }
         for (size_t i = 0; i < devices.size(); ++i) part_[i].comm = comms[i];
         for (size_t i = 1; i < devices.size(); ++i) threads_.emplace_back(&multi::worker, this, (int)i);
     } catch (...) {
