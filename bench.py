@@ -1116,16 +1116,19 @@ def main():
             # the native leg takes the devices this process can see: all `world` of them under RCCL (one rank per GPU), fewer when a
             # gloo rehearsal shared GPUs or the launcher masked the devices per rank
             n_native = min(world, max(ndev, 1))
-            nm = run_native_child(n_native, args, "grouped")
+            # Over several devices the collective is issued by one thread per device (tolfg_multi ISSUE_THREADS): the group bracket is
+            # serial work of ~18 us per device for one thread -- 150 us per step at eight devices, more than configs[3]'s and configs[4]'s
+            # shards take to run (profiles/r05_native_multi.md, "What a step costs the HOST").  The bracket form (the library's default)
+            # is measured too, in a process of its own, headline and configs.
+            first = "threads" if n_native > 1 else "grouped"
+            nm = run_native_child(n_native, args, first)
             if left:
                 nm["ranks_still_alive_at_start"] = left
             if n_native != world:
                 nm["note_devices"] = f"{world} ranks, {ndev} device(s) visible to rank 0: the native leg ran over {n_native}"
             line["native_multi"] = nm
             if n_native > 1 and "error" not in nm:
-                # the other way of issuing the collective (one call per device thread: no rendezvous of the host threads per step,
-                # which is what a 12 us launch per device wants), in a process of its own
-                line["native_multi_threads"] = run_native_child(n_native, args, "threads", timeout=300)
+                line["native_multi_grouped"] = run_native_child(n_native, args, "grouped", timeout=300)
         sys.stdout.flush()
         data = (json.dumps(line) + "\n").encode()
         while data:

@@ -42,7 +42,7 @@ if "headline_same_x_every_step" in d:
     c = d["headline_same_x_every_step"]
     print("  side: the headline with the same X buffer every step (x from the Infinity Cache): %.1f us per launch = %.3f of peak over the same algorithmic bytes"
           % (1e3 * c["kernel_ms"], c["frac_of_hbm_peak"]))
-for key in ("native_multi", "native_multi_threads"):
+for key in ("native_multi", "native_multi_grouped", "native_multi_threads"):
     if key in d:
         c = d[key]
         if "error" in c:
