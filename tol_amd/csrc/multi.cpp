@@ -203,6 +203,7 @@ void multi::release()
         std::lock_guard<std::mutex> lk(mu_);
         quit_ = true;
         ++generation_;
+        gen_hint_.store(generation_, std::memory_order_release);
     }
     cv_go_.notify_all();
     for (std::thread &t : threads_) t.join();
@@ -261,12 +262,30 @@ void multi::free_buffers()
     }
 }
 
+namespace {
+// A short spin before a condition-variable sleep: in a step loop the next job (or the last worker's completion) is a few
+// microseconds away, and a futex sleep + wake costs 10-20 us of latency per hand-over (measured: 3 us per step with one part, 16-26
+// with worker threads in play, profiles/r05_native_multi.md).  Bounded: 30 us, then the thread sleeps like before.
+template <typename Pred>
+bool spin_until(Pred &&ready)
+{
+    using clk = std::chrono::steady_clock;
+    const auto t0 = clk::now();
+    for (int i = 0;; ++i) {
+        if (ready()) return true;
+        __builtin_ia32_pause();
+        if ((i & 63) == 63 && clk::now() - t0 > std::chrono::microseconds(30)) return false;
+    }
+}
+}  // namespace
+
 void multi::worker(int i)
 {
     unsigned long seen = 0;
     (void)hipSetDevice(part_[i].device);
     for (;;) {
         const std::function<void(Part &)> *job = nullptr;
+        (void)spin_until([&] { return gen_hint_.load(std::memory_order_acquire) != seen; });
         {
             std::unique_lock<std::mutex> lk(mu_);
             cv_go_.wait(lk, [&] { return generation_ != seen; });
@@ -284,6 +303,7 @@ void multi::worker(int i)
             std::lock_guard<std::mutex> lk(mu_);
             if (!err.empty()) errors_.push_back("device " + std::to_string(part_[i].device) + ": " + err);
             --pending_;
+            pending_hint_.store(pending_, std::memory_order_release);
         }
         cv_done_.notify_one();
     }
@@ -296,8 +316,10 @@ void multi::on_every_device(const std::function<void(Part &)> &fn)
         std::lock_guard<std::mutex> lk(mu_);
         job_ = &fn;
         pending_ = (int)threads_.size();
+        pending_hint_.store(pending_, std::memory_order_relaxed);
         errors_.clear();
         ++generation_;
+        gen_hint_.store(generation_, std::memory_order_release);
     }
     cv_go_.notify_all();
     std::string mine;
@@ -307,6 +329,7 @@ void multi::on_every_device(const std::function<void(Part &)> &fn)
     } catch (const std::exception &e) {
         mine = std::string("device ") + std::to_string(part_[0].device) + ": " + e.what();
     }
+    (void)spin_until([&] { return pending_hint_.load(std::memory_order_acquire) == 0; });
     std::unique_lock<std::mutex> lk(mu_);
     cv_done_.wait(lk, [&] { return pending_ == 0; });
     if (!mine.empty()) errors_.insert(errors_.begin(), mine);

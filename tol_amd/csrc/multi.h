@@ -168,6 +168,8 @@ private:
     std::condition_variable cv_go_, cv_done_;
     unsigned long generation_ = 0;
     int pending_ = 0;
+    std::atomic<unsigned long> gen_hint_{0};     // copies of generation_ / pending_ for the short spin before a sleep (multi.cpp: spin_until);
+    std::atomic<int> pending_hint_{0};           // the mutex-guarded values stay the truth
     bool quit_ = false;
     const std::function<void(Part &)> *job_ = nullptr;
     std::vector<std::string> errors_;
