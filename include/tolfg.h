@@ -298,12 +298,12 @@ int  tolfg_batch_objectives(tolfg_batch *b, int B, const void *dF, long ldf, voi
  *   tolfg_device_alloc / tolfg_device_free: device memory in that form (falls back to hipMalloc where the runtime has no
  *     virtual-memory support) -- for X, F, G or anything else; a pointer from it is an ordinary device pointer;
  *   tolfg_batch_alloc_outputs: the G buffer of B trajectories ([B][*ldg] elements of the batch dtype, *ldg = the row length
- *     rounded up to 16 bytes), PLACED for this batch's launch: up to `tries` candidates (1..16, and never more than fit side by side into half of the free device memory; the Python layer and tolfg_multi take 12: ~0.05 s each) from
+ *     rounded up to 16 bytes), PLACED for this batch's launch: up to `tries` candidates (1..16, and never more than fit side by side into half of the free device memory; the Python layer and tolfg_multi take 12: ~0.2 s each at 1.4 GB, most of it the settling of the fresh block) from
  *     tolfg_device_alloc, held side by side, each timed with the bare store loop of the launch's own shape
  *     (tolfg_batch_set_store_shape); the search ends early once a candidate is 18 % faster than the slowest seen (fast and slow
  *     class are ~20 % apart); the fastest is kept, the rest freed.  probe_us (NULL or [tries]) receives the candidates' times in us, *tried (NULL or int)
  *     how many were timed -- 1 and no timing when the launch's outputs fit the cache, where placement does not matter.
- *     Blocking, tens of ms: set-up time.  Free the buffer with tolfg_device_free.
+ *     Blocking, up to a few seconds for a dozen gigabyte-sized candidates: set-up time.  Free the buffer with tolfg_device_free.
  * Buffers from anywhere else keep working; they just take the class they land in. */
 /* A block comes SETTLED and zeroed: the driver wipes video memory it gets back with a copy job of its own and may hand the chunks out
  * again before that job has run, so that a fresh block was seen to go back to 0.0, chunk by chunk, milliseconds after a kernel had
@@ -395,7 +395,7 @@ enum { TOLFG_MULTI_GATHER_RCCL = 0, TOLFG_MULTI_GATHER_HOST = 1 };
 int  tolfg_multi_set_gather(tolfg_multi *m, int mode);
 /* Candidates of the per-device placement search for the G buffers (tolfg_batch_alloc_outputs) that the NEXT
  * tolfg_multi_set_trajectories runs, the devices searching side by side on their own threads: default 12 (each device holds
- * its candidates within half of its free memory, ~0.05 s per candidate); 0 or 1 = one allocation, no search. */
+ * its candidates within half of its free memory, ~0.2 s per 1.4 GB candidate); 0 or 1 = one allocation, no search. */
 int  tolfg_multi_set_placement(tolfg_multi *m, int tries);
 /* Measurement aid (bench.py --native-multi): `warm` untimed steps, then `steps` steps issued from native code between two
  * full synchronisations.  A step = one launch per device (+ the asynchronous gather when gather != 0).  dX: n_x sets of

@@ -401,7 +401,7 @@ void multi::set_trajectories(long total, const tolfg_traj *trajs, int place_trie
         check(hipMalloc(&p.dX, elem() * rows * ldx_), "hipMalloc(X)");
         check(hipMalloc(&p.dF, elem() * rows * ldf_), "hipMalloc(F)");
         // G, the bulk of what a launch writes, comes placed for this shard's launch (problem.h: alloc_outputs): up to
-        // place_tries candidates per device, held side by side within half of its free memory, ~0.05 s each, the devices
+        // place_tries candidates per device, held side by side within half of its free memory, ~0.2 s each at 1.4 GB, the devices
         // searching concurrently on their own threads
         if (B > 0) {
             long ldg = 0;
