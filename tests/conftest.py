@@ -10,6 +10,21 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "multigpu: needs a node with SEVERAL MI355X (run with -m multigpu there; never part of -m gpu: the "
+                                       "build sessions' boxes have one GPU, so these tests have not run yet)")
+
+
+def pytest_collection_modifyitems(config, items):
+    """The `multigpu` tests (tests/test_multi_real_devices.py) are collected only when asked for by name (`-m multigpu`): they belong
+    neither to the CPU run (`-m "not gpu"`) nor to the one-GPU run (`-m gpu`)."""
+    if "multigpu" in (config.getoption("-m") or ""):
+        return
+    keep, drop = [], []
+    for it in items:
+        (drop if it.get_closest_marker("multigpu") else keep).append(it)
+    if drop:
+        config.hook.pytest_deselected(items=drop)
+        items[:] = keep
 
 
 @pytest.fixture(scope="session")

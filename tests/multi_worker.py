@@ -12,6 +12,12 @@ sys.path.insert(0, os.path.dirname(HERE))
 sys.path.insert(0, HERE)
 
 
+def device_list(parts):
+    """Device ordinal of every part: all on device 0 under the shared-devices seam (loop-back collectives, one-GPU box), else
+    one real device each (tests/test_multi_real_devices.py, a node with several GPUs)."""
+    return [0] * parts if os.environ.get("TOLFG_MULTI_SHARED_DEVICES") == "1" else list(range(parts))
+
+
 def trajectories(tolfg, mission, total):
     ms = [("S10", "G7")[t % 2] if mission == "mixed" else mission for t in range(total)]
     return [tolfg.Trajectory(aircraft=t % 2, mission=ms[t], radius_goal=100.0 if ms[t] == "S10" else 0.0, Vref=0.4 + 0.1 * t,
@@ -34,7 +40,8 @@ def pipeline(out, mission, dtype, total, parts, N, issue, gather="rccl"):
     import tol_amd as tolfg
     air = ["tempest", "skywalker"]
     trajs = trajectories(tolfg, mission, total)
-    m = tolfg.Multi(mission, air, ts=N, dtype=dtype, devices=[0] * parts)
+    devs = device_list(parts)
+    m = tolfg.Multi(mission, air, ts=N, dtype=dtype, devices=devs)
     m.set_issue(issue)
     m.set_gather(gather)
     m.set_placement(2)
@@ -50,14 +57,16 @@ def pipeline(out, mission, dtype, total, parts, N, issue, gather="rccl"):
         for i in range(parts):
             lo, hi = m.shard(i)
             (dX, ldx), _, _ = m.buffers(i)
-            base = torch.as_tensor(_Raw(dX, (max(hi - lo, 1), ldx), "<f8" if dtype == "f64" else "<f4"), device="cuda:0")
+            with torch.cuda.device(devs[i]):
+                base = torch.as_tensor(_Raw(dX, (max(hi - lo, 1), ldx), "<f8" if dtype == "f64" else "<f4"), device=torch.device("cuda", devs[i]))
             assert base.data_ptr() == dX
             x = base.clone()
             x[:, 1:] *= 1.0 + 2e-3 * j           # set 0 = the initial guesses themselves
             keep.append(x)
             ptrs.append(x.data_ptr())
         sets.append(ptrs)
-    torch.cuda.synchronize()
+    for d in set(devs):
+        torch.cuda.synchronize(d)
     tickets, got = [], []
     for j in range(nsteps):
         tickets.append(m.step(dX=sets[j]))
@@ -110,7 +119,7 @@ def pipeline(out, mission, dtype, total, parts, N, issue, gather="rccl"):
         assert poisoned[1, 1 + 11 * 7 + 10].view(torch.int64).item() == np.float64(marker).view(np.int64)
         bad_set = list(sets[0])
         bad_set[part] = poisoned.data_ptr()
-        torch.cuda.synchronize()
+        torch.cuda.synchronize(devs[part])
         m.step(dX=bad_set)                                             # runs; that shard's status word gets set
         m.sync()
         try:
@@ -146,7 +155,7 @@ def main():
     air = ["tempest", "skywalker"]
     wm = tolfg.capi.WIND_TABLE if wind == "table" else tolfg.capi.WIND_SHEAR
     trajs = trajectories(tolfg, mission, total)
-    m = tolfg.Multi(mission, air, ts=N, dtype=dtype, devices=[0] * parts, windmodel=wm)
+    m = tolfg.Multi(mission, air, ts=N, dtype=dtype, devices=device_list(parts), windmodel=wm)
     res = {"library": np.array(m.rccl_library())}
     m.set_trajectories(trajs)
     res["shards"] = np.array([m.shard(i) for i in range(parts)])
