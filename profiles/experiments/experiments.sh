@@ -951,12 +951,14 @@ done
 find "$OUT" -name "*.csv" -size +2M -delete
 ;;
 r04_alloc_probe)
-# One allocation probe per call (tools/alloc_probe.py ... alloc_probe8.py; $2 = 1 ... 8, further arguments are the probe's own, e.g. "3 order"):
-# where the output buffer lands decides the class the launch runs in (profiles/r04_allocation_classes.md).
+# One allocation probe per call ($2 = 1 ... 8, further arguments are the probe's own, e.g. "3 order"): where the output buffer lands decides
+# the class the launch runs in (profiles/r04_allocation_classes.md).  Round 5 kept tools/alloc_probe.py (n = 1) only; probes 2 ... 10 are in the
+# history (git show a2af350:tools/alloc_probeN.py), their outputs under profiles/r04/.
 set -u
 n=${2:-7}
 shift; shift || true
 tool=tools/alloc_probe$([ "$n" = 1 ] || echo "$n").py
+[ -f "$tool" ] || { echo "$tool was removed in round 5: git show a2af350:$tool > $tool"; exit 1; }
 mkdir -p gpurun_out/r04_alloc
 timeout -k 10 400 python3 "$tool" "$@" 2>&1 | grep -v amdgpu.ids | tee "gpurun_out/r04_alloc/probe_$n.txt"
 ;;
@@ -1037,7 +1039,7 @@ r04_callback_tiles     the callback (B = 1) as one workgroup vs tile workgroups 
 r04_incache_counters   what binds launches whose outputs fit the cache: rocprofv3 stats + one counter per pass, B = 1024 / 2048  [r04_incache_counters.md]
 r04_fp32_traffic       where the extra 4.6 % of HBM bytes of the fp32 launches come from: write / read request counters, mixed / S10 / G7 / fp64  [r04_fp32_traffic.md]
 r04_align_counters     write requests with the slab streams cut to 64-byte boundaries (r04_stream_align64.patch applied) vs the 16-byte form  [r04_fp32_traffic.md]
-r04_alloc_probe N      one of the allocation probes tools/alloc_probe.py ... alloc_probe8.py (N = 1 ... 8; further arguments are the probe's own)  [r04_allocation_classes.md]
+r04_alloc_probe N      one of round 4's allocation probes (N = 1: tools/alloc_probe.py; 2 ... 8 live in the history since round 5; further arguments are the probe's own)  [r04_allocation_classes.md]
 r04_x0_time            initial guesses on the device: serial walk vs the table-driven node-parallel kernel, bitwise test first  [r04_x0_kernel.md]
 LIST
 ;;
