@@ -971,10 +971,12 @@ def main():
                     opts.is_high_priority_stream = True
                 except Exception:      # noqa: BLE001
                     opts = None
+                import datetime
+                limit = datetime.timedelta(seconds=300)      # a collective that never completes ends the run with an error, not a hang
                 try:
-                    dist.init_process_group("nccl", device_id=torch.device("cuda", local), pg_options=opts)
+                    dist.init_process_group("nccl", device_id=torch.device("cuda", local), pg_options=opts, timeout=limit)
                 except TypeError:
-                    dist.init_process_group("nccl")
+                    dist.init_process_group("nccl", timeout=limit)
                 probe = torch.ones(1, device="cuda")
                 dist.all_reduce(probe)
                 torch.cuda.synchronize()
